@@ -1,0 +1,151 @@
+/*
+ * vo_hip.h -- C ABI of the MI355X (gfx950) visual-odometry hot-path library.
+ *
+ * The reference (VOxFF/visual_odometry) is pure Python; its plugin boundary is a
+ * set of abstract base classes, and the arithmetic behind them is NumPy, PyTorch
+ * and the RAFT / RAFT-Stereo submodules.  Each entry point below replaces the
+ * arithmetic behind one of those interface methods (cited per function), so a
+ * Python subclass of the reference's own ABC can forward to it through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - tensors are dense, row-major, float32 unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     all work is enqueued asynchronously on it, nothing synchronises;
+ *   - return value: VO_OK (0) or a negative VO_ERR_* code; the text of the last
+ *     error on the calling thread is available from vo_last_error();
+ *   - the library never allocates, frees or retains caller memory.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_OK                0
+#define VO_ERR_INVALID_ARG  -1   /* null pointer, non-positive size, unsupported shape */
+#define VO_ERR_LAUNCH       -2   /* the HIP runtime rejected the launch               */
+#define VO_ERR_UNSUPPORTED  -3   /* shape outside what the kernels were built for     */
+
+#define VO_MAX_LEVELS 4          /* corr_levels=4: stereo/stereo_disparity_RAFT.py:40 */
+
+/* Library version as major*10000 + minor*100 + patch. */
+int vo_version(void);
+/* Message for the last non-zero status returned on this thread ("" if none). */
+const char* vo_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * All-pairs correlation volume (RAFT CorrBlock / RAFT-Stereo CorrBlock1D "reg").
+ * Call sites in the reference: flow/flow_map_RAFT.py:15,42,81 and
+ * stereo/stereo_disparity_RAFT.py:15,39,46,91 (the model code itself lives in
+ * un-vendored submodules).
+ *
+ * Feature maps are PIXEL-MAJOR: fmap[b][y][x][d], d contiguous (channels-last).
+ * f32 MFMA (v_mfma_f32_32x32x2_f32), i.e. exact float32 multiply-accumulate.
+ *
+ * 2-D: corr[b][y1*W+x1][y2*W+x2] = <f1[b,y1,x1,:], f2[b,y2,x2,:]> / sqrt(D)
+ * 1-D: corr[b][y][x1][x2]        = <f1[b,y,x1,:],  f2[b,y,x2,:]>  / sqrt(D)
+ * D must be a multiple of 32.
+ * ------------------------------------------------------------------------- */
+int vo_corr_volume_2d(const float* fmap1, const float* fmap2, float* corr,
+                      int batch, int H, int W, int D, void* stream);
+int vo_corr_volume_1d(const float* fmap1, const float* fmap2, float* corr,
+                      int batch, int H, int W1, int W2, int D, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Correlation pyramid: levels 1..3 from level 0 in one pass (avg_pool 2x2 / 1x2,
+ * stride 2, floor sizes).  `images` = batch*H*W source pixels, each owning an
+ * (H2 x W2) slice (2-D) or a W2 row (1-D).  Unused upper levels may be NULL.
+ * ------------------------------------------------------------------------- */
+int vo_corr_pyramid_2d(const float* l0, float* l1, float* l2, float* l3,
+                       int64_t images, int H2, int W2, void* stream);
+int vo_corr_pyramid_1d(const float* l0, float* l1, float* l2, float* l3,
+                       int64_t rows, int W2, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Windowed correlation lookup (CorrBlock.__call__ / CorrBlock1D.__call__).
+ * coords: (B,2,H,W) (x,y) in level-0 pixels of the target frame.
+ * 2-D out: (B, levels*(2r+1)^2, H, W); channel = l*(2r+1)^2 + a*(2r+1) + b samples
+ *          level l at (x/2^l + a - r, y/2^l + b - r), bilinear, zeros outside,
+ *          pixel-centre coordinates (grid_sample align_corners=True).
+ * 1-D out: (B, levels*(2r+1), H, W); channel = l*(2r+1) + a samples the row at
+ *          x/2^l + a - r (only coords channel 0 is read).
+ * pyr[l] is level l as produced above; level sizes are floor-halved from (H2,W2).
+ * ------------------------------------------------------------------------- */
+int vo_corr_lookup_2d(const float* l0, const float* l1, const float* l2, const float* l3,
+                      const float* coords, float* out, int batch, int H, int W,
+                      int H2, int W2, int levels, int radius, void* stream);
+int vo_corr_lookup_1d(const float* l0, const float* l1, const float* l2, const float* l3,
+                      const float* coords, float* out, int batch, int H, int W,
+                      int W2, int levels, int radius, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Convex upsampling (RAFT.upsample_flow / RAFTStereo.upsample_flow).
+ * flow: (B,Cf,H,W); mask: (B, 9*f*f, H, W) raw logits times mask_scale;
+ * out:  (B,Cout,f*H,f*W) with Cout <= Cf leading channels (stereo keeps 1).
+ * out[b,c,f*y+i,f*x+j] = sum_k softmax_k(mask[b,k*f*f+i*f+j,y,x]) * f*flow[b,c,y+k/3-1,x+k%3-1]
+ * ------------------------------------------------------------------------- */
+int vo_convex_upsample(const float* flow, const float* mask, float* out,
+                       int batch, int Cf, int Cout, int H, int W, int factor,
+                       float mask_scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * StereoDepth.compute_depth -- stereo/stereo_depth.py:25-49.
+ * depth = fxB/|d| where |d| > 0 else 0.  divide_in_f64 != 0 reproduces NumPy's
+ * float64 quotient rounded once to float32 (np.float64 fx, baseline); 0 divides in
+ * float32 with fxB rounded to float32 first (plain Python floats).
+ * ------------------------------------------------------------------------- */
+int vo_disparity_to_depth(const float* disparity, float* depth, int64_t n,
+                          double fxB, int divide_in_f64, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Keypoint stages.  kp: (N,2) float64 (x,y), shared by all B items when
+ * kp_batch_stride == 0, else item b starts at kp + b*kp_batch_stride doubles.
+ * depth maps (B,H,W), flow (B,2,H,W); Kinv_host = 9 doubles, row-major, on the host.
+ * Masks are uint8 0/1 (NumPy bool layout).
+ *
+ * vo_keypoints_to_3d      Keypoints3DXform.to_3d        keypoints/keypoints_3d.py:20-49
+ * vo_keypoints_flow_2d    Keypoints3DFlow.compute_2d_flow keypoints/keypoints_3d_flow.py:23-47
+ * vo_keypoints_flow_3d    Keypoints3DFlow.compute_3d_flow keypoints/keypoints_3d_flow.py:49-88
+ *                         (p1_out, the frame-1 lift the reference computes and drops, may be NULL)
+ * vo_pair_correspondences test_camera_tracking.py:176-200 for B pairs at once:
+ *                         P1 = lift(kp, depth1); P2 = 3-D flow; weight = in depth
+ *                         range & flow-valid & |Z2-Z1| <= max_dz; n_in_range[b] = points
+ *                         left after the range filter (the "< 4 -> skip" test, :188).
+ * ------------------------------------------------------------------------- */
+int vo_keypoints_to_3d(const double* kp, int64_t kp_batch_stride, const float* depth,
+                       const double* Kinv_host, double* points_out,
+                       int batch, int N, int H, int W, void* stream);
+int vo_keypoints_flow_2d(const double* kp, int64_t kp_batch_stride, const float* flow,
+                         double* next_out, uint8_t* valid_out,
+                         int batch, int N, int H, int W, void* stream);
+int vo_keypoints_flow_3d(const double* kp, int64_t kp_batch_stride,
+                         const float* depth1, const float* depth2, const float* flow,
+                         const double* Kinv_host, double* p2_out, uint8_t* valid_out,
+                         double* p1_out, int batch, int N, int H, int W, void* stream);
+int vo_pair_correspondences(const double* kp, int64_t kp_batch_stride,
+                            const float* depth1, const float* depth2, const float* flow,
+                            const double* Kinv_host, double min_depth, double max_depth,
+                            double max_dz, double* p1_out, double* p2_out,
+                            uint8_t* weight_out, int32_t* n_in_range_out,
+                            int batch, int N, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * CameraSvdXform.compute_camera_xform -- camera/camera_svd_xform.py:18-48,
+ * batched: one 64-lane wavefront per pair.
+ * P, Q: (B,N,3) float64; weight: (B,N) uint8 or NULL (all ones);
+ * offset_host: 3 doubles on the host or NULL.
+ * T_out: (B,4,4) float64 row-major [R t; 0 0 0 1] with Q ~ R P + t (+ R offset);
+ * n_used_out: (B) int32 number of weighted points, or NULL.
+ * ------------------------------------------------------------------------- */
+int vo_kabsch_batch(const double* P, const double* Q, const uint8_t* weight,
+                    const double* offset_host, double* T_out, int32_t* n_used_out,
+                    int batch, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

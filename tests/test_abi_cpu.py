@@ -1,0 +1,104 @@
+"""The C-ABI shared library on a machine without a GPU: it loads, exports every
+symbol ``include/vo_hip.h`` declares, and rejects bad arguments before touching
+the device.  Also: the host-side pieces of the package that need no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "vo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from visual_odometry_amd import _lib
+    names = _declared()
+    assert len(names) >= 15
+    assert names == _lib.EXPORTS                      # the ctypes table covers the header exactly
+    lib = _lib.load()
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert _lib.version() == 100
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from visual_odometry_amd import _lib
+    lib = _lib.load()
+    assert lib.vo_kabsch_batch(None, None, None, None, None, None, 1, 3, None) == _lib.VO_ERR_INVALID_ARG
+    assert b"null" in lib.vo_last_error()
+    assert lib.vo_disparity_to_depth(None, None, 10, 1.0, 1, None) == _lib.VO_ERR_INVALID_ARG
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.vo_corr_volume_2d(p, p, p, 1, 2, 2, 48, None) == _lib.VO_ERR_UNSUPPORTED   # D % 32 != 0
+    assert b"multiple of 32" in lib.vo_last_error()
+    assert lib.vo_corr_lookup_2d(p, None, None, None, p, p, 1, 2, 2, 2, 2, 1, 7, None) == _lib.VO_ERR_UNSUPPORTED
+    assert lib.vo_convex_upsample(p, p, p, 1, 2, 2, 2, 2, 3, 1.0, None) == _lib.VO_ERR_UNSUPPORTED
+    assert lib.vo_corr_pyramid_2d(p, None, p, None, 1, 4, 4, None) == _lib.VO_ERR_INVALID_ARG
+    with pytest.raises(ValueError):
+        _lib.call("vo_keypoints_to_3d", None, 0, None, None, None, 1, 1, 4, 4, None)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from visual_odometry_amd import ops
+    with pytest.raises(ValueError, match="GPU tensor"):
+        ops.disparity_to_depth(torch.zeros(8), 1.0)
+    with pytest.raises(ValueError, match="GPU tensor"):
+        ops.corr_volume_2d(torch.zeros(1, 2, 2, 32), torch.zeros(1, 2, 2, 32))
+
+
+def test_plugins_need_a_gpu_and_say_so():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from visual_odometry_amd.geometry import HipCameraSvdXform
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        HipCameraSvdXform().compute_camera_xform(np.zeros((4, 3)), np.ones((4, 3)))
+
+
+def test_host_rotation_fit_matches_lapack():
+    """The 3x3 rotation fit of the Kabsch kernel, compiled for the host."""
+    from oracle import geometry_ref as ref
+    from tests.golden import cases
+    so = os.path.join(ROOT, "tests", "_host_checks.so")
+    if not os.path.exists(so):
+        from visual_odometry_amd.build import build_host_checks
+        build_host_checks()
+    lib = ctypes.CDLL(so)
+    fit = lib.host_rotation_from_covariance
+    fit.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+
+    def rot(P, Q):
+        H = np.ascontiguousarray((P - P.mean(0)).T @ (Q - Q.mean(0)))
+        R = np.zeros((3, 3))
+        fit(H.ctypes.data, R.ctypes.data)
+        return R
+
+    for name, (P, Q, _) in cases.kabsch_cases().items():
+        R = rot(P, Q)
+        assert np.abs(R - ref.kabsch(P, Q)[0]).max() < 1e-12, name
+        assert abs(np.linalg.det(R) - 1) < 1e-12
+    # degenerate covariances still give a proper rotation
+    for H in (np.zeros((3, 3)), np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0]), np.diag([3.0, 2.0, 0.0])):
+        R = np.zeros((3, 3))
+        H = np.ascontiguousarray(H)
+        fit(H.ctypes.data, R.ctypes.data)
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+
+
+def test_uniform_keypoints_host_matches_golden():
+    from tests.conftest import golden
+    from tests.golden import cases
+    from visual_odometry_amd.geometry import UniformKeyPoints
+    g = golden("g1_keypoint_grid")
+    for (h, w, n, margin) in cases.GRID_CASES:
+        for mname, mask in cases.grid_masks(h, w, seed=h + n + margin).items():
+            got = UniformKeyPoints(mask, margin).get_keypoints(None, n)
+            assert np.array_equal(got, g[f"{h}x{w}_n{n}_m{margin}_{mname}"])

@@ -1,0 +1,264 @@
+"""HIP correlation / pyramid / lookup / upsample kernels (through the C ABI)
+against the stock-PyTorch oracle, operator by operator and end to end.
+
+Parity for this half is UNPINNED by the reference (its RAFT submodules are
+empty; see oracle/raft_ref.py): the oracle is this repository's restatement.
+Tolerances: volume / lookup / upsample <= 1e-4 absolute on O(1) values,
+end-to-end flow / disparity <= 0.05 px mean end-point error (north star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import raft_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _nchw(pm):          # pixel-major (B,H,W,D) -> (B,D,H,W)
+    return pm.permute(0, 3, 1, 2).contiguous()
+
+
+# ---------------------------------------------------------------- correlation
+
+@pytest.mark.parametrize("B,H,W,D", [(2, 12, 20, 256), (1, 7, 10, 64), (1, 16, 16, 32), (1, 60, 80, 256)])
+def test_corr_volume_2d(vo, B, H, W, D):
+    from visual_odometry_amd import ops
+    f1, f2 = _rand(B, H, W, D, seed=1), _rand(B, H, W, D, seed=2)
+    got = ops.corr_volume_2d(f1.to(DEV), f2.to(DEV))
+    assert got.shape == (B, H * W, H, W)
+    want = raft_ref.corr_volume_2d(_nchw(f1).double(), _nchw(f2).double()).float()
+    assert (got.cpu() - want).abs().max().item() < 2e-5
+    # transposing the roles transposes the volume bit for bit (same k order, a*b == b*a)
+    swapped = ops.corr_volume_2d(f2.to(DEV), f1.to(DEV))
+    assert torch.equal(swapped.view(B, H * W, H * W).transpose(1, 2), got.view(B, H * W, H * W))
+
+
+def test_corr_volume_exact_on_integers(vo):
+    """Small-integer features make every product and partial sum exact in float32:
+    any operand-layout or tile-index slip shows up as a wrong integer.  fmap2 is
+    not symmetric in anything, so a transposed write cannot hide."""
+    from visual_odometry_amd import ops
+    B, H, W, D = 1, 9, 65, 256            # 585 pixels: five 128-tiles, the last partial
+    g = torch.Generator().manual_seed(3)
+    f1 = torch.randint(-3, 4, (B, H, W, D), generator=g).float()
+    f2 = torch.randint(-3, 4, (B, H, W, D), generator=g).float()
+    got = ops.corr_volume_2d(f1.to(DEV), f2.to(DEV)).cpu().view(H * W, H * W)
+    want = (f1.view(H * W, D).double() @ f2.view(H * W, D).double().T / 16.0).float()
+    assert torch.equal(got, want)
+    # 1-D flavour, widths that are not multiples of the 32-wide MFMA tile
+    f1 = torch.randint(-3, 4, (2, 5, 50, 64), generator=g).float()
+    f2 = torch.randint(-3, 4, (2, 5, 37, 64), generator=g).float()
+    got = ops.corr_volume_1d(f1.to(DEV), f2.to(DEV)).cpu()
+    want = (torch.einsum("bhid,bhjd->bhij", f1.double(), f2.double()) / 8.0).float()
+    assert got.shape == (2, 5, 50, 37) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,H,W,D", [(2, 6, 160, 256), (1, 3, 40, 256), (1, 2, 320, 256), (1, 2, 200, 128)])
+def test_corr_volume_1d(vo, B, H, W, D):
+    from visual_odometry_amd import ops
+    f1, f2 = _rand(B, H, W, D, seed=4), _rand(B, H, W, D, seed=5)
+    got = ops.corr_volume_1d(f1.to(DEV), f2.to(DEV))
+    want = raft_ref.corr_volume_1d(_nchw(f1).double(), _nchw(f2).double()).float()
+    assert got.shape == (B, H, W, W)
+    assert (got.cpu() - want).abs().max().item() < 2e-5
+
+
+def test_corr_rejects_bad_input(vo):
+    from visual_odometry_amd import ops
+    from visual_odometry_amd._lib import VoHipError
+    with pytest.raises(VoHipError):          # feature dim not a multiple of 32
+        ops.corr_volume_2d(torch.zeros(1, 4, 4, 48, device=DEV), torch.zeros(1, 4, 4, 48, device=DEV))
+    with pytest.raises(ValueError):
+        ops.corr_volume_2d(torch.zeros(1, 4, 4, 64), torch.zeros(1, 4, 4, 64))      # CPU tensors
+    with pytest.raises(ValueError):
+        ops.corr_volume_2d(torch.zeros(1, 4, 4, 64, device=DEV), torch.zeros(1, 4, 5, 64, device=DEV))
+
+
+# -------------------------------------------------------------------- pyramid
+
+@pytest.mark.parametrize("B,N,H,W", [(1, 50, 60, 80), (2, 7, 15, 21), (1, 3, 9, 8), (1, 5, 90, 160), (1, 4, 6, 7)])
+def test_pyramid_2d(vo, B, N, H, W):
+    from visual_odometry_amd import ops
+    levels = 4 if min(H, W) >= 8 else 3 if min(H, W) >= 4 else 2
+    c = _rand(B, N, H, W, seed=6)
+    got = ops.corr_pyramid_2d(c.to(DEV), levels)
+    want = raft_ref.corr_pyramid_2d(c, levels)
+    assert len(got) == levels
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        torch.testing.assert_close(g.cpu(), w, rtol=1e-6, atol=1e-6)
+    # averaging is linear: pyramid(a + 2b) == pyramid(a) + 2 pyramid(b) up to rounding
+    d = _rand(B, N, H, W, seed=7)
+    pd = ops.corr_pyramid_2d(d.to(DEV), levels)
+    ps = ops.corr_pyramid_2d((c + 2 * d).to(DEV), levels)
+    for a, b, s in zip(got, pd, ps):
+        torch.testing.assert_close(s, a + 2 * b, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W1,W2", [(1, 4, 160, 160), (2, 3, 10, 37), (1, 2, 5, 320), (1, 1, 3, 9)])
+def test_pyramid_1d(vo, B, H, W1, W2):
+    from visual_odometry_amd import ops
+    c = _rand(B, H, W1, W2, seed=8)
+    got = ops.corr_pyramid_1d(c.to(DEV), 4)
+    want = raft_ref.corr_pyramid_1d(c, 4)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        torch.testing.assert_close(g.cpu(), w, rtol=1e-6, atol=1e-6)
+
+
+# --------------------------------------------------------------------- lookup
+
+def _coords(B, H, W, seed, spread):
+    base = raft_ref.coords_grid(B, H, W)
+    c = base + _rand(B, 2, H, W, seed=seed, scale=spread)
+    # hand-placed cases: exact integers, just outside each border, far outside
+    c[0, :, 0, 0] = torch.tensor([0.0, 0.0])
+    c[0, :, 0, 1] = torch.tensor([-0.5, -0.5])
+    c[0, :, 0, 2] = torch.tensor([W - 1.0, H - 1.0])
+    c[0, :, 0, 3] = torch.tensor([W - 0.5, H + 3.25])
+    c[0, :, 0, 4] = torch.tensor([-100.0, 50.0])
+    c[0, :, 0, 5] = torch.tensor([3.0, 1e6])
+    return c
+
+
+@pytest.mark.parametrize("B,H,W,radius,levels", [(1, 12, 20, 4, 4), (2, 8, 16, 3, 3), (1, 60, 80, 4, 4)])
+def test_lookup_2d(vo, B, H, W, radius, levels):
+    from visual_odometry_amd import ops
+    N = H * W
+    if N > 1000:                      # full 640x480 geometry: build the volume on the GPU
+        f1, f2 = _rand(B, H, W, 64, seed=9), _rand(B, H, W, 64, seed=10)
+        pyr = ops.corr_pyramid_2d(ops.corr_volume_2d(f1.to(DEV), f2.to(DEV)), levels)
+    else:
+        pyr = ops.corr_pyramid_2d(_rand(B, N, H, W, seed=9).to(DEV), levels)
+    coords = _coords(B, H, W, 11, 3.0)
+    got = ops.corr_lookup_2d(pyr, coords.to(DEV), radius)
+    assert got.shape == (B, levels * (2 * radius + 1) ** 2, H, W)
+    # float64 oracle: removes the normalise/un-normalise rounding of grid_sample
+    want = raft_ref.corr_lookup_2d([p.cpu().double() for p in pyr], coords.double(), radius)
+    assert (got.cpu().double() - want).abs().max().item() < 2e-5
+    # and the float32 stock operator itself agrees to its own rounding
+    want32 = raft_ref.corr_lookup_2d([p.cpu() for p in pyr], coords, radius)
+    assert (got.cpu() - want32).abs().max().item() < 5e-4
+    # integer coordinates reproduce volume entries exactly (weights 1 and 0)
+    ci = raft_ref.coords_grid(B, H, W)
+    exact = ops.corr_lookup_2d(pyr[:1], ci.to(DEV), radius).cpu()
+    centre = radius * (2 * radius + 1) + radius
+    diag = pyr[0].cpu().view(B, N, N).diagonal(dim1=1, dim2=2).reshape(B, H, W)
+    assert torch.equal(exact[:, centre], diag)
+
+
+@pytest.mark.parametrize("B,H,W,radius", [(1, 6, 40, 4), (2, 4, 37, 3), (1, 120, 160, 4)])
+def test_lookup_1d(vo, B, H, W, radius):
+    from visual_odometry_amd import ops
+    pyr = ops.corr_pyramid_1d(_rand(B, H, W, W, seed=12).to(DEV), 4)
+    coords = _coords(B, H, W, 13, 5.0)
+    got = ops.corr_lookup_1d(pyr, coords.to(DEV), radius)
+    assert got.shape == (B, 4 * (2 * radius + 1), H, W)
+    want = raft_ref.corr_lookup_1d([p.cpu().double() for p in pyr], coords.double(), radius)
+    assert (got.cpu().double() - want).abs().max().item() < 2e-5
+
+
+def test_lookup_rejects_mismatched_pyramid(vo):
+    from visual_odometry_amd import ops
+    pyr = ops.corr_pyramid_2d(torch.zeros(1, 48, 6, 8, device=DEV), 2)
+    with pytest.raises(ValueError):
+        ops.corr_lookup_2d(pyr, torch.zeros(1, 2, 6, 9, device=DEV))
+    with pytest.raises(ValueError):
+        ops.corr_lookup_2d([pyr[0], pyr[0]], torch.zeros(1, 2, 6, 8, device=DEV))
+    from visual_odometry_amd._lib import VoHipError
+    with pytest.raises(VoHipError):
+        ops.corr_lookup_2d(pyr, torch.zeros(1, 2, 6, 8, device=DEV), radius=5)
+
+
+# ------------------------------------------------------------------- upsample
+
+@pytest.mark.parametrize("B,C,Cout,H,W,f", [(2, 2, 2, 12, 20, 8), (1, 2, 1, 30, 40, 4), (1, 2, 2, 5, 7, 2),
+                                           (1, 2, 2, 60, 80, 8), (1, 2, 1, 120, 160, 4)])
+def test_convex_upsample(vo, B, C, Cout, H, W, f):
+    from visual_odometry_amd import ops
+    flow = _rand(B, C, H, W, seed=14, scale=3.0)
+    mask = _rand(B, 9 * f * f, H, W, seed=15, scale=4.0)
+    got = ops.convex_upsample(flow.to(DEV), mask.to(DEV), f, out_channels=Cout, mask_scale=0.25)
+    want = raft_ref.convex_upsample(flow, 0.25 * mask, f)[:, :Cout]
+    assert got.shape == (B, Cout, f * H, f * W)
+    assert (got.cpu() - want).abs().max().item() < 2e-5
+    # a convex combination of a constant field is that constant (times f)
+    const = torch.full((B, C, H, W), 1.5)
+    up = ops.convex_upsample(const.to(DEV), mask.to(DEV), f, out_channels=Cout).cpu()
+    inner = up[:, :, f:-f, f:-f]
+    assert (inner - 1.5 * f).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------- whole networks
+
+def _epe(a, b):
+    return (a - b).pow(2).sum(1).sqrt().mean().item()
+
+
+def _images(B, H, W, seed):
+    from visual_odometry_amd import synthetic as syn
+    left, right = syn.stereo_sequence(seed, B + 1, H, W)
+    to = lambda a: torch.from_numpy(a).float()[:, None].expand(-1, 3, -1, -1).contiguous().to(DEV)
+    return to(left), to(right)
+
+
+@pytest.mark.parametrize("H,W,iters", [(128, 160, 4), (480, 640, 12)])
+def test_raft_flow_end_to_end(vo, H, W, iters):
+    from visual_odometry_amd.raft.models import RAFTFlow
+    torch.manual_seed(0)
+    model = RAFTFlow().to(DEV).eval()
+    left, _ = _images(2, H, W, seed=5)
+    lo, up = model(left[:2], left[1:3], iters=iters)
+    lo_ref, up_ref = raft_ref.raft_flow_forward(model, left[:2], left[1:3], iters=iters)
+    assert up.shape == (2, 2, H, W)
+    assert _epe(up, up_ref) < 0.05 and _epe(lo, lo_ref) < 0.05 / 8
+    assert float(up.abs().max()) > 1e-3        # the network actually moved
+    # shared-frame feature maps (sequence mode) give the same flow
+    from visual_odometry_amd.raft.models import normalize_image
+    fm = model.features(normalize_image(left))
+    lo2, up2 = model(left[:2], left[1:3], iters=iters, fmap1=fm[:2].contiguous(), fmap2=fm[1:3].contiguous())
+    assert _epe(up2, up) < 1e-3
+
+
+@pytest.mark.parametrize("H,W,iters,realtime", [(128, 160, 4, True), (128, 160, 3, False), (480, 640, 12, True)])
+def test_raft_stereo_end_to_end(vo, H, W, iters, realtime):
+    from visual_odometry_amd.raft.models import RAFTStereo, RAFTStereoConfig
+    torch.manual_seed(1)
+    model = RAFTStereo(RAFTStereoConfig.realtime() if realtime else RAFTStereoConfig()).to(DEV).eval()
+    left, right = _images(1, H, W, seed=6)
+    lo, disp = model(left, right, iters=iters)
+    lo_ref, disp_ref = raft_ref.raft_stereo_forward(model, left, right, iters=iters)
+    assert disp.shape == (2, 1, H, W)
+    assert (disp - disp_ref).abs().mean().item() < 0.05
+    assert float(lo[:, 1].abs().max()) == 0.0       # epipolar constraint: no y motion
+    assert float(disp.abs().max()) > 1e-3
+
+
+def test_plugin_wrappers(vo):
+    from visual_odometry_amd import synthetic as syn
+    from visual_odometry_amd.raft.models import RAFTStereoConfig
+    from visual_odometry_amd.raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT
+    left, right = syn.stereo_sequence(3, 2, 100, 130)          # needs padding: 100x130 -> 104x136 / 128x160
+    flow_solver = HipOpticalFlowRAFT(None, None, iters=2)
+    flow = flow_solver.compute_flow(left[0], left[1])
+    assert flow.shape == (2, 100, 130) and flow.dtype == np.float32
+    bgr = np.repeat(left[0][:, :, None], 3, axis=2)
+    assert np.allclose(flow_solver.compute_flow(bgr, np.repeat(left[1][:, :, None], 3, axis=2)), flow, atol=1e-4)
+    with pytest.raises(ValueError):
+        flow_solver.compute_flow(None, left[1])
+    with pytest.raises(TypeError):
+        flow_solver.compute_flow([1, 2], left[1])
+    disp_solver = HipDisparityRAFT(None, None, iters=2, config=RAFTStereoConfig.realtime())
+    disp = disp_solver.compute_disparity(left[0], right[0])
+    assert disp.shape == (100, 130) and disp.dtype == np.float32
+    with pytest.raises(ValueError):
+        disp_solver.compute_disparity(left[0], None)
+    with pytest.raises(TypeError):
+        disp_solver.compute_disparity(left[0], 7)

@@ -1,0 +1,79 @@
+"""ctypes binding of ``lib/libvo_hip.so`` (the C ABI declared in ``include/vo_hip.h``).
+
+There is no CPU fallback: if the shared library has not been built, or a kernel
+is called without a GPU tensor, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libvo_hip.so")
+
+VO_OK, VO_ERR_INVALID_ARG, VO_ERR_LAUNCH, VO_ERR_UNSUPPORTED = 0, -1, -2, -3
+
+_P, _I, _L, _D, _F = c_void_p, c_int, c_int64, c_double, c_float
+
+# name -> argtypes; every function returns int except the two below.
+SIGNATURES = {
+    "vo_corr_volume_2d": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vo_corr_volume_1d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vo_corr_pyramid_2d": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "vo_corr_pyramid_1d": [_P, _P, _P, _P, _L, _I, _P],
+    "vo_corr_lookup_2d": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_corr_lookup_1d": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_convex_upsample": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vo_disparity_to_depth": [_P, _P, _L, _D, _I, _P],
+    "vo_keypoints_to_3d": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vo_keypoints_flow_2d": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vo_keypoints_flow_3d": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vo_pair_correspondences": [_P, _L, _P, _P, _P, _P, _D, _D, _D, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vo_kabsch_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+}
+EXPORTS = sorted(list(SIGNATURES) + ["vo_version", "vo_last_error"])
+
+_lib = None
+
+
+class VoHipError(RuntimeError):
+    """A HIP launch was rejected or a shape is outside what the kernels support."""
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m visual_odometry_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    lib.vo_version.argtypes = []
+    lib.vo_version.restype = c_int
+    lib.vo_last_error.argtypes = []
+    lib.vo_last_error.restype = c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an entry point and turn its status into the reference's exceptions:
+    invalid arguments -> ValueError, anything else -> VoHipError."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc == VO_OK:
+        return
+    msg = lib.vo_last_error().decode("utf-8", "replace")
+    if rc == VO_ERR_INVALID_ARG:
+        raise ValueError(msg)
+    raise VoHipError(f"{name} failed ({rc}): {msg}")
+
+
+def version() -> int:
+    return load().vo_version()

@@ -1,0 +1,214 @@
+// All-pairs correlation volume: batched C[g] = (A[g] * B[g]^T) / sqrt(K) on the
+// gfx950 matrix cores with float32 operands (v_mfma_f32_32x32x2_f32, which is an
+// exact float32 multiply-accumulate chain, so the volume carries no precision
+// loss against the reference's float32 matmul).
+//
+// A[g]: M x K, B[g]: N x K, both row-major with K contiguous (pixel-major feature
+// maps), C[g]: M x N.  RAFT-Flow:   g = pair, M = N = H*W/64 pixels.
+//                       RAFT-Stereo: g = (pair, image row), M = N = W/4 pixels.
+//
+// Workgroup = WAVES_M x WAVES_N waves, each wave owning TM x TN MFMA tiles of
+// 32x32.  Feature tiles are staged global -> registers -> LDS (rows padded to
+// BK+4 floats so the 16-byte fragment reads are bank-conflict free) with the next
+// K-slice's global loads in flight while the current one is multiplied.
+//
+// Fragment trick: the MFMA takes A[i][k] from lane (i = lane&31, k = lane>>5).
+// Which physical k feeds which (half, step) slot is irrelevant as long as A and B
+// agree, so each lane reads FOUR consecutive k values with one ds_read_b128
+// (k = 8*group + 4*(lane>>5) + step) and feeds them to four successive MFMAs.
+#include "vo_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PAD = 4;   // floats of row padding in LDS
+
+// Bijective XCD-aware remap: the dispatcher deals consecutive workgroups round
+// robin over the 8 XCDs; give each XCD one contiguous range of the work list so
+// that the feature rows it touches stay in its own L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+    int64_t strideA, int64_t strideB, int64_t strideC, int tiles_m, int tiles_n, unsigned nwg, float divisor) {
+    constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+    constexpr int TM = BM / (32 * WAVES_M);
+    constexpr int TN = BN / (32 * WAVES_N);
+    constexpr int LDS_STRIDE = BK + PAD;
+    constexpr int A_F4 = BM * BK / 4 / THREADS;      // float4 loads per thread per K-slice
+    constexpr int B_F4 = BN * BK / 4 / THREADS;
+    static_assert(BM % (32 * WAVES_M) == 0 && BN % (32 * WAVES_N) == 0, "tile / wave mismatch");
+    static_assert((BM * BK / 4) % THREADS == 0 && (BN * BK / 4) % THREADS == 0, "staging mismatch");
+    static_assert(BK % 8 == 0, "BK must be a multiple of 8");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [2][BM][LDS_STRIDE]
+    float* Bs = smem + 2 * BM * LDS_STRIDE;             // [2][BN][LDS_STRIDE]
+
+    const unsigned work = xcd_remap(blockIdx.x, nwg);
+    const int tn = work % tiles_n;
+    const int tm = (work / tiles_n) % tiles_m;
+    const int g = work / (tiles_n * tiles_m);
+    const float* Ag = A + g * strideA;
+    const float* Bg = B + g * strideB;
+    float* Cg = C + g * strideC;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // staging: float4 slot f -> (row f / (BK/4), column group f % (BK/4)); rows past
+    // the matrix edge re-read the last valid row (their products are never stored)
+    float4 ra[A_F4], rb[B_F4];
+#define VO_LOAD_SLICE(k0)                                                                                   \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < A_F4; ++i_) {                                               \
+            const int f_ = tid + i_ * THREADS;                                                              \
+            const int r_ = min(row0 + f_ / (BK / 4), M - 1);                                                \
+            ra[i_] = *reinterpret_cast<const float4*>(Ag + (int64_t)r_ * K + (k0) + (f_ % (BK / 4)) * 4);   \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_F4; ++i_) {                                               \
+            const int f_ = tid + i_ * THREADS;                                                              \
+            const int r_ = min(col0 + f_ / (BK / 4), N - 1);                                                \
+            rb[i_] = *reinterpret_cast<const float4*>(Bg + (int64_t)r_ * K + (k0) + (f_ % (BK / 4)) * 4);   \
+        }                                                                                                   \
+    } while (0)
+#define VO_STORE_SLICE(buf)                                                                                 \
+    do {                                                                                                    \
+        float* as_ = As + (buf) * BM * LDS_STRIDE;                                                          \
+        float* bs_ = Bs + (buf) * BN * LDS_STRIDE;                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < A_F4; ++i_) {                                               \
+            const int f_ = tid + i_ * THREADS;                                                              \
+            *reinterpret_cast<float4*>(as_ + (f_ / (BK / 4)) * LDS_STRIDE + (f_ % (BK / 4)) * 4) = ra[i_];  \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_F4; ++i_) {                                               \
+            const int f_ = tid + i_ * THREADS;                                                              \
+            *reinterpret_cast<float4*>(bs_ + (f_ / (BK / 4)) * LDS_STRIDE + (f_ % (BK / 4)) * 4) = rb[i_];  \
+        }                                                                                                   \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+    VO_LOAD_SLICE(0);
+    VO_STORE_SLICE(0);
+    __syncthreads();
+
+    // one K-slice of MFMAs out of LDS buffer `buf`
+#define VO_MMA_SLICE(buf)                                                                                          \
+    do {                                                                                                           \
+        const float* as_ = As + (buf) * BM * LDS_STRIDE + (wm * TM * 32 + lr) * LDS_STRIDE + 4 * lh;               \
+        const float* bs_ = Bs + (buf) * BN * LDS_STRIDE + (wn * TN * 32 + lr) * LDS_STRIDE + 4 * lh;               \
+        _Pragma("unroll") for (int kg = 0; kg < BK / 8; ++kg) {                                                    \
+            float4 fa[TM], fb[TN];                                                                                 \
+            _Pragma("unroll") for (int m = 0; m < TM; ++m)                                                         \
+                fa[m] = *reinterpret_cast<const float4*>(as_ + m * 32 * LDS_STRIDE + kg * 8);                      \
+            _Pragma("unroll") for (int n = 0; n < TN; ++n)                                                         \
+                fb[n] = *reinterpret_cast<const float4*>(bs_ + n * 32 * LDS_STRIDE + kg * 8);                      \
+            _Pragma("unroll") for (int m = 0; m < TM; ++m) _Pragma("unroll") for (int n = 0; n < TN; ++n) {        \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m].x, fb[n].x, acc[m][n], 0, 0, 0);            \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m].y, fb[n].y, acc[m][n], 0, 0, 0);            \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m].z, fb[n].z, acc[m][n], 0, 0, 0);            \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m].w, fb[n].w, acc[m][n], 0, 0, 0);            \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+
+    const int slices = K / BK;
+    for (int s = 0; s + 1 < slices; ++s) {
+        const int buf = s & 1;
+        VO_LOAD_SLICE((s + 1) * BK);          // global loads in flight during the MFMAs below
+        VO_MMA_SLICE(buf);
+        VO_STORE_SLICE(buf ^ 1);              // the other buffer: nobody reads it in this phase
+        __syncthreads();
+    }
+    VO_MMA_SLICE((slices - 1) & 1);
+#undef VO_MMA_SLICE
+#undef VO_LOAD_SLICE
+#undef VO_STORE_SLICE
+
+    // C/D layout of the 32x32 MFMA: column = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // Per register the two wave halves each write 32 consecutive floats of one row.
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = col0 + (wn * TN + n) * 32 + lr;
+            const int rbase = row0 + (wm * TM + m) * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + (e & 3) + 8 * (e >> 2);
+                if (row < M && col < N) Cg[(int64_t)row * N + col] = acc[m][n][e] / divisor;
+            }
+        }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+int launch_corr(const float* A, const float* B, float* C, int groups, int M, int N, int K, int64_t sA,
+                int64_t sB, int64_t sC, float divisor, hipStream_t stream, const char* name) {
+    const int tiles_m = (int)vo_ceil_div(M, BM), tiles_n = (int)vo_ceil_div(N, BN);
+    const int64_t nwg = (int64_t)tiles_m * tiles_n * groups;
+    if (nwg > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: %lld workgroups", name, (long long)nwg);
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + PAD) * sizeof(float);
+    auto kern = corr_abt_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: LDS attribute: %s", name, hipGetErrorString(e));
+        attr_done = true;
+    }
+    kern<<<dim3((unsigned)nwg), dim3(64 * WAVES_M * WAVES_N), lds, stream>>>(A, B, C, M, N, K, sA, sB, sC, tiles_m,
+                                                                             tiles_n, (unsigned)nwg, divisor);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
+    return VO_OK;
+}
+
+int corr_abt(const float* A, const float* B, float* C, int groups, int M, int N, int K, int64_t sA, int64_t sB,
+             int64_t sC, hipStream_t stream, const char* name) {
+    if (!A || !B || !C) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if (groups <= 0 || M <= 0 || N <= 0 || K <= 0)
+        return vo_fail(VO_ERR_INVALID_ARG, "%s: non-positive size (groups=%d M=%d N=%d K=%d)", name, groups, M, N, K);
+    if (K % 32 != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: feature dim %d is not a multiple of 32", name, K);
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15)
+        return vo_fail(VO_ERR_INVALID_ARG, "%s: feature maps must be 16-byte aligned", name);
+    const float divisor = sqrtf((float)K);      // corr / sqrt(dim), divided as the reference does
+    // Small matrices (one image row of RAFT-Stereo) get one 160-wide tile per
+    // workgroup; the big flow volume gets 128x128 tiles.
+    if (M <= 512 && N <= 512)
+        return launch_corr<160, 160, 16, 1, 5>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+    return launch_corr<128, 128, 32, 2, 2>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+}
+
+}  // namespace
+
+extern "C" int vo_corr_volume_2d(const float* fmap1, const float* fmap2, float* corr, int batch, int H, int W,
+                                 int D, void* stream) {
+    VO_REQUIRE(H > 0 && W > 0, "vo_corr_volume_2d: bad size H=%d W=%d", H, W);
+    const int64_t n = (int64_t)H * W;
+    VO_REQUIRE(n <= (1 << 20), "vo_corr_volume_2d: %lld pixels per feature map is beyond the supported 2^20", (long long)n);
+    return corr_abt(fmap1, fmap2, corr, batch, (int)n, (int)n, D, n * D, n * D, n * n, vo_stream(stream),
+                    "vo_corr_volume_2d");
+}
+
+extern "C" int vo_corr_volume_1d(const float* fmap1, const float* fmap2, float* corr, int batch, int H, int W1,
+                                 int W2, int D, void* stream) {
+    VO_REQUIRE(batch > 0 && H > 0, "vo_corr_volume_1d: bad size batch=%d H=%d", batch, H);
+    VO_REQUIRE((int64_t)batch * H <= 0x7fffffffLL, "vo_corr_volume_1d: batch*H too large");
+    return corr_abt(fmap1, fmap2, corr, batch * H, W1, W2, D, (int64_t)W1 * D, (int64_t)W2 * D, (int64_t)W1 * W2,
+                    vo_stream(stream), "vo_corr_volume_1d");
+}

@@ -1,0 +1,195 @@
+"""HIP-backed drop-ins for the reference's geometry plugins.
+
+Each class keeps the reference's constructor and method signatures (host NumPy in,
+freshly allocated host NumPy out, same exceptions) and adds ``*_batch`` methods
+that take and return GPU tensors so a whole chunk of frame pairs stays in HBM.
+
+  HipStereoDepth        stereo/stereo_depth.py:4-49
+  UniformKeyPoints      keypoints/keypoints_uniform.py:4-59   (host, once per mask)
+  HipKeypoints3DXform   keypoints/keypoints_3d.py:5-70
+  HipKeypoints3DFlow    keypoints/keypoints_3d_flow.py:8-88
+  HipCameraSvdXform     camera/camera_svd_xform.py:4-48
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .interfaces import (CameraXformInterface, KeyPointsInterface, Keypoints3DFlowInterface,
+                         Keypoints3DInterface, StereoParamsInterface)
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("the HIP backend needs a visible AMD GPU (there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_gpu(a, dtype) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(_device())
+
+
+# --------------------------------------------------------------------------- depth
+
+class HipStereoDepth:
+    """depth = fx * baseline / |disparity|, zero where the disparity is zero."""
+
+    def __init__(self, params):
+        if not isinstance(params, StereoParamsInterface):
+            raise ValueError("params must be an instance of StereoParamsInterface")
+        self.fx = params.focal_length_px
+        self.baseline = params.get_baseline()
+        if self.fx <= 0 or self.baseline <= 0:
+            raise ValueError("Focal length and baseline must be positive values.")
+        fxB = self.fx * self.baseline
+        # NumPy evaluates float64-scalar / float32-array in float64 and rounds once
+        # on assignment; a Python-float or float32 product divides in float32.
+        self._f64 = isinstance(fxB, np.float64)
+        self._fxB = float(fxB)
+
+    def compute_depth(self, disparity):
+        if disparity is None:
+            raise ValueError("Disparity map is None.")
+        d = np.asarray(disparity)
+        out = self.compute_depth_batch(_to_gpu(d, np.float32))
+        return out.cpu().numpy().reshape(d.shape)
+
+    def compute_depth_batch(self, disparity: torch.Tensor) -> torch.Tensor:
+        """Any-shape float32 GPU tensor of disparities -> depths, same shape."""
+        return ops.disparity_to_depth(disparity, self._fxB, self._f64)
+
+
+# ----------------------------------------------------------------------- keypoints
+
+class UniformKeyPoints(KeyPointsInterface):
+    """Aspect-aware uniform grid inside a validity mask.  The grid depends only on
+    the mask, so it is built once on the host and cached (host and device)."""
+
+    def __init__(self, rectification_mask: np.ndarray, margin: int = 0):
+        self.rectification_mask = rectification_mask
+        self.margin = margin
+        self._cache = {}
+
+    def get_keypoints(self, image, max_number: int) -> np.ndarray:
+        key = int(max_number)
+        if key not in self._cache:
+            self._cache[key] = self._build(key)
+        return self._cache[key].copy()
+
+    def get_keypoints_device(self, max_number: int) -> torch.Tensor:
+        """The same grid as an (N,2) float64 GPU tensor (exact: |index| < 2^53)."""
+        return _to_gpu(self.get_keypoints(None, max_number), np.float64)
+
+    def _build(self, max_number: int) -> np.ndarray:
+        mask = self.rectification_mask
+        rows, cols = mask.shape
+        left, right = self.margin, cols - self.margin
+        top, bottom = self.margin, rows - self.margin
+        wide, tall = right - left, bottom - top
+        count_x = int(np.sqrt(max_number * (wide / tall)))
+        count_y = int(np.sqrt(max_number * (tall / wide)))
+        gx = np.linspace(left, right - 1, count_x).astype(int)
+        gy = np.linspace(top, bottom - 1, count_y).astype(int)
+        grid = np.stack([np.tile(gx, count_y), np.repeat(gy, count_x)], axis=-1)
+        grid = grid[mask[grid[:, 1], grid[:, 0]]]
+        if len(grid) > max_number:
+            grid = grid[np.linspace(0, len(grid) - 1, max_number, dtype=int)]
+        return grid
+
+
+def _check_indexable(kp: np.ndarray, h: int, w: int):
+    """The reference indexes depth[int(v), int(u)]; NumPy raises IndexError outside
+    [-n, n).  The kernels never fault on such input, but the drop-in reports it."""
+    if kp.size == 0:
+        return
+    iu = np.trunc(kp[:, 0]); iv = np.trunc(kp[:, 1])
+    if not (np.all(np.isfinite(kp)) and iu.min() >= -w and iu.max() < w and iv.min() >= -h and iv.max() < h):
+        raise IndexError("keypoint outside the image")
+
+
+class HipKeypoints3DXform(Keypoints3DInterface):
+    def __init__(self, camera_params):
+        self.camera_params = camera_params
+        self.K_inv = np.linalg.inv(self.camera_params.K)
+
+    def to_3d(self, keypoints: np.ndarray, depth_map: np.ndarray) -> np.ndarray:
+        if depth_map.ndim != 2:
+            raise ValueError("depth_map must be a 2D array.")
+        kp = np.asarray(keypoints)
+        if kp.shape[0] == 0:
+            return np.array([])
+        kp = kp.astype(np.float64).reshape(-1, 2)
+        _check_indexable(kp, *depth_map.shape)
+        out = self.to_3d_batch(_to_gpu(kp, np.float64), _to_gpu(depth_map, np.float32)[None])
+        return out[0].cpu().numpy()
+
+    def to_3d_batch(self, keypoints: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
+        """(N,2)|(B,N,2) float64 keypoints, (B,H,W) float32 depth -> (B,N,3) float64."""
+        return ops.keypoints_to_3d(keypoints, depth, self.K_inv)
+
+    def to_2d(self, points_3D: np.ndarray) -> np.ndarray:
+        """Pinhole projection; rows with Z <= 0 are dropped, so the result can be
+        shorter than the input (keypoints/keypoints_3d.py:61-70).  Only the viewers
+        call this, so it stays on the host."""
+        pts = np.asarray(points_3D, dtype=np.float64).reshape(-1, 3)
+        pts = pts[pts[:, 2] > 0]
+        if pts.shape[0] == 0:
+            return np.array([])
+        K = np.asarray(self.camera_params.K, dtype=np.float64)
+        xn = pts[:, 0] / pts[:, 2]; yn = pts[:, 1] / pts[:, 2]
+        return np.stack([K[0, 0] * xn + K[0, 1] * yn + K[0, 2],
+                         K[1, 0] * xn + K[1, 1] * yn + K[1, 2]], axis=1)
+
+
+class HipKeypoints3DFlow(Keypoints3DFlowInterface):
+    def __init__(self, camera_params, keypoints_xform, rectification_mask: np.ndarray):
+        self.camera_params = camera_params
+        self.keypoints_xform = keypoints_xform
+        self.rectification_mask = rectification_mask
+        k_inv = getattr(keypoints_xform, "K_inv", None)
+        self.K_inv = np.linalg.inv(camera_params.K) if k_inv is None else k_inv
+
+    def compute_2d_flow(self, keypoints: np.ndarray, uv_flow: np.ndarray):
+        kp = np.asarray(keypoints).astype(np.float64).reshape(-1, 2)
+        _check_indexable(kp, uv_flow.shape[1], uv_flow.shape[2])
+        nxt, valid = ops.keypoints_flow_2d(_to_gpu(kp, np.float64), _to_gpu(uv_flow, np.float32)[None])
+        return nxt[0].cpu().numpy(), valid[0].cpu().numpy()
+
+    def compute_3d_flow(self, keypoints, depth1, depth2, uv_flow):
+        kp = np.asarray(keypoints).astype(np.float64).reshape(-1, 2)
+        _check_indexable(kp, uv_flow.shape[1], uv_flow.shape[2])
+        p2, ok = self.compute_3d_flow_batch(_to_gpu(kp, np.float64), _to_gpu(depth1, np.float32)[None],
+                                            _to_gpu(depth2, np.float32)[None], _to_gpu(uv_flow, np.float32)[None])
+        return p2[0].cpu().numpy(), ok[0].cpu().numpy()
+
+    def compute_3d_flow_batch(self, keypoints, depth1, depth2, flow):
+        """GPU tensors: depth (B,H,W), flow (B,2,H,W) -> points (B,N,3) f64, mask (B,N) bool."""
+        return ops.keypoints_flow_3d(keypoints, depth1, depth2, flow, self.K_inv)
+
+    def pair_correspondences_batch(self, keypoints, depth1, depth2, flow,
+                                   min_depth=0.0, max_depth=15.0, max_dz=1.0):
+        """The tracking loop's point selection (test_camera_tracking.py:176-200) for B
+        pairs: P1, P2 (B,N,3) f64, weight (B,N) uint8, n_in_range (B) int32."""
+        return ops.pair_correspondences(keypoints, depth1, depth2, flow, self.K_inv,
+                                        min_depth, max_depth, max_dz)
+
+
+# ---------------------------------------------------------------------------- pose
+
+class HipCameraSvdXform(CameraXformInterface):
+    """Kabsch fit Q ~ R P + t with the camera-offset correction t += R offset."""
+
+    def __init__(self, offset=np.array([0.0, 0.0, 0.0])):
+        self.offset = np.array(offset)
+
+    def compute_camera_xform(self, P: np.ndarray, Q: np.ndarray):
+        T, _ = self.compute_camera_xform_batch(_to_gpu(np.asarray(P)[None], np.float64),
+                                               _to_gpu(np.asarray(Q)[None], np.float64))
+        T = T[0].cpu().numpy()
+        return T[:3, :3].copy(), T[:3, 3].copy()
+
+    def compute_camera_xform_batch(self, P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None):
+        """(B,N,3) float64 GPU point sets (+ optional (B,N) uint8 weights) ->
+        T (B,4,4) float64, n_used (B) int32."""
+        return ops.kabsch_batch(P, Q, weight, self.offset)

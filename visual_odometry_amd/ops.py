@@ -1,0 +1,269 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype/device checks on the host,
+output allocation through PyTorch's caching allocator, launch on torch's
+current stream.  PyTorch is only the memory/stream plumbing here; all the
+arithmetic is in ``csrc/*.hip``.
+
+Every function takes and returns CUDA (ROCm) tensors and raises when handed a
+CPU tensor: there is deliberately no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_LEVELS = 4
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype: torch.dtype) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor (the HIP backend has no CPU path)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t, name, dtype) -> int:
+    return 0 if t is None else _dev(t, name, dtype)
+
+
+def _host9(Kinv) -> "ctypes.Array":
+    a = np.ascontiguousarray(np.asarray(Kinv, dtype=np.float64)).reshape(-1)
+    if a.size != 9:
+        raise ValueError("K_inv must have 9 elements")
+    return (ctypes.c_double * 9)(*a.tolist())
+
+
+# ------------------------------------------------------------------ RAFT ops
+
+def pyramid_shapes_2d(h2: int, w2: int, levels: int = MAX_LEVELS):
+    out = [(h2, w2)]
+    for _ in range(levels - 1):
+        out.append((out[-1][0] // 2, out[-1][1] // 2))
+    return out
+
+
+def corr_volume_2d(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+    """All-pairs correlation of two pixel-major feature maps (B,H,W,D) ->
+    (B, H*W, H, W) float32, scaled by 1/sqrt(D)."""
+    B, H, W, D = fmap1.shape
+    if fmap2.shape != fmap1.shape:
+        raise ValueError("fmap1 and fmap2 must have the same shape")
+    corr = torch.empty((B, H * W, H, W), device=fmap1.device, dtype=torch.float32)
+    _lib.call("vo_corr_volume_2d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+              corr.data_ptr(), B, H, W, D, _stream())
+    return corr
+
+
+def corr_volume_1d(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+    """Per-row all-pairs correlation (B,H,W1,D) x (B,H,W2,D) -> (B,H,W1,W2)."""
+    B, H, W1, D = fmap1.shape
+    if fmap2.shape[0] != B or fmap2.shape[1] != H or fmap2.shape[3] != D:
+        raise ValueError("fmap2 must be (B,H,W2,D) matching fmap1")
+    W2 = fmap2.shape[2]
+    corr = torch.empty((B, H, W1, W2), device=fmap1.device, dtype=torch.float32)
+    _lib.call("vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+              corr.data_ptr(), B, H, W1, W2, D, _stream())
+    return corr
+
+
+def corr_pyramid_2d(corr: torch.Tensor, levels: int = MAX_LEVELS):
+    """[(B,N,H2,W2) level 0, ...floor-halved levels] from the level-0 volume."""
+    if not 1 <= levels <= MAX_LEVELS:
+        raise ValueError("levels must be in 1..4")
+    B, N, H2, W2 = corr.shape
+    shapes = pyramid_shapes_2d(H2, W2, levels)
+    pyr = [corr] + [torch.empty((B, N, h, w), device=corr.device, dtype=torch.float32) for h, w in shapes[1:]]
+    ptrs = [p.data_ptr() for p in pyr[1:]] + [0] * (MAX_LEVELS - levels)
+    if levels > 1:
+        _lib.call("vo_corr_pyramid_2d", _dev(corr, "corr", torch.float32), *ptrs, B * N, H2, W2, _stream())
+    return pyr
+
+
+def corr_pyramid_1d(corr: torch.Tensor, levels: int = MAX_LEVELS):
+    """[(B,H,W1,W2), (B,H,W1,W2//2), ...] from the level-0 row volume."""
+    if not 1 <= levels <= MAX_LEVELS:
+        raise ValueError("levels must be in 1..4")
+    B, H, W1, W2 = corr.shape
+    widths = [W2]
+    for _ in range(levels - 1):
+        widths.append(widths[-1] // 2)
+    pyr = [corr] + [torch.empty((B, H, W1, w), device=corr.device, dtype=torch.float32) for w in widths[1:]]
+    ptrs = [p.data_ptr() for p in pyr[1:]] + [0] * (MAX_LEVELS - levels)
+    if levels > 1:
+        _lib.call("vo_corr_pyramid_1d", _dev(corr, "corr", torch.float32), *ptrs, B * H * W1, W2, _stream())
+    return pyr
+
+
+def _level_ptrs(pyr):
+    if not 1 <= len(pyr) <= MAX_LEVELS:
+        raise ValueError("pyramid must have 1..4 levels")
+    return [_dev(p, f"pyr[{i}]", torch.float32) for i, p in enumerate(pyr)] + [0] * (MAX_LEVELS - len(pyr))
+
+
+def corr_lookup_2d(pyr, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Windowed bilinear lookup -> (B, L*(2r+1)^2, H, W)."""
+    B, two, H, W = coords.shape
+    _, N, H2, W2 = pyr[0].shape
+    if two != 2 or N != H * W or pyr[0].shape[0] != B:
+        raise ValueError("coords must be (B,2,H,W) with H*W source pixels matching the pyramid")
+    for i, (h, w) in enumerate(pyramid_shapes_2d(H2, W2, len(pyr))):
+        if tuple(pyr[i].shape) != (B, N, h, w):
+            raise ValueError(f"pyramid level {i} has shape {tuple(pyr[i].shape)}, expected {(B, N, h, w)}")
+    win = 2 * radius + 1
+    ch = len(pyr) * win * win
+    if out is None:
+        out = torch.empty((B, ch, H, W), device=coords.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, ch, H, W):
+        raise ValueError("out has the wrong shape")
+    _lib.call("vo_corr_lookup_2d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
+              _dev(out, "out", torch.float32), B, H, W, H2, W2, len(pyr), radius, _stream())
+    return out
+
+
+def corr_lookup_1d(pyr, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Windowed linear lookup along x -> (B, L*(2r+1), H, W); reads coords[:,0]."""
+    B, two, H, W = coords.shape
+    if two != 2 or tuple(pyr[0].shape[:3]) != (B, H, W):
+        raise ValueError("coords must be (B,2,H,W) matching the (B,H,W1,W2) pyramid")
+    W2 = pyr[0].shape[3]
+    w = W2
+    for i, p in enumerate(pyr):
+        if tuple(p.shape) != (B, H, W, w):
+            raise ValueError(f"pyramid level {i} has shape {tuple(p.shape)}, expected {(B, H, W, w)}")
+        w //= 2
+    ch = len(pyr) * (2 * radius + 1)
+    if out is None:
+        out = torch.empty((B, ch, H, W), device=coords.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, ch, H, W):
+        raise ValueError("out has the wrong shape")
+    _lib.call("vo_corr_lookup_1d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
+              _dev(out, "out", torch.float32), B, H, W, W2, len(pyr), radius, _stream())
+    return out
+
+
+def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, factor: int, out_channels: int | None = None,
+                    mask_scale: float = 1.0) -> torch.Tensor:
+    """Convex-combination upsampling -> (B, Cout, f*H, f*W)."""
+    B, Cf, H, W = flow.shape
+    if tuple(mask.shape) != (B, 9 * factor * factor, H, W):
+        raise ValueError(f"mask must be (B,{9 * factor * factor},H,W)")
+    Cout = Cf if out_channels is None else out_channels
+    if not 1 <= Cout <= Cf:
+        raise ValueError("out_channels must be in 1..flow channels")
+    out = torch.empty((B, Cout, factor * H, factor * W), device=flow.device, dtype=torch.float32)
+    _lib.call("vo_convex_upsample", _dev(flow, "flow", torch.float32), _dev(mask, "mask", torch.float32),
+              out.data_ptr(), B, Cf, Cout, H, W, factor, float(mask_scale), _stream())
+    return out
+
+
+# -------------------------------------------------------------- geometry ops
+
+def disparity_to_depth(disparity: torch.Tensor, fxB: float, divide_in_f64: bool = True) -> torch.Tensor:
+    depth = torch.empty_like(disparity)
+    _lib.call("vo_disparity_to_depth", _dev(disparity, "disparity", torch.float32), depth.data_ptr(),
+              disparity.numel(), float(fxB), int(bool(divide_in_f64)), _stream())
+    return depth
+
+
+def _kp_args(kp: torch.Tensor, batch: int):
+    """(N,2) shared grid or (B,N,2) per-item keypoints, float64 -> (ptr, stride, N)."""
+    p = _dev(kp, "keypoints", torch.float64)
+    if kp.dim() == 2 and kp.shape[1] == 2:
+        return p, 0, kp.shape[0]
+    if kp.dim() == 3 and kp.shape[0] == batch and kp.shape[2] == 2:
+        return p, kp.shape[1] * 2, kp.shape[1]
+    raise ValueError("keypoints must be (N,2) or (B,N,2)")
+
+
+def keypoints_to_3d(kp: torch.Tensor, depth: torch.Tensor, K_inv) -> torch.Tensor:
+    """(B,H,W) depth + keypoints -> (B,N,3) float64."""
+    if depth.dim() != 3:
+        raise ValueError("depth must be (B,H,W)")
+    B, H, W = depth.shape
+    p, stride, N = _kp_args(kp, B)
+    out = torch.empty((B, N, 3), device=depth.device, dtype=torch.float64)
+    _lib.call("vo_keypoints_to_3d", p, stride, _dev(depth, "depth", torch.float32), _host9(K_inv),
+              out.data_ptr(), B, N, H, W, _stream())
+    return out
+
+
+def keypoints_flow_2d(kp: torch.Tensor, flow: torch.Tensor):
+    """(B,2,H,W) flow -> next (B,N,2) float64, valid (B,N) bool."""
+    if flow.dim() != 4 or flow.shape[1] != 2:
+        raise ValueError("flow must be (B,2,H,W)")
+    B, _, H, W = flow.shape
+    p, stride, N = _kp_args(kp, B)
+    nxt = torch.empty((B, N, 2), device=flow.device, dtype=torch.float64)
+    valid = torch.empty((B, N), device=flow.device, dtype=torch.uint8)
+    _lib.call("vo_keypoints_flow_2d", p, stride, _dev(flow, "flow", torch.float32), nxt.data_ptr(),
+              valid.data_ptr(), B, N, H, W, _stream())
+    return nxt, valid.bool()
+
+
+def _check_maps(depth1, depth2, flow):
+    if flow.dim() != 4 or flow.shape[1] != 2:
+        raise ValueError("flow must be (B,2,H,W)")
+    B, _, H, W = flow.shape
+    if tuple(depth1.shape) != (B, H, W) or tuple(depth2.shape) != (B, H, W):
+        raise ValueError("depth maps must be (B,H,W) matching the flow")
+    return B, H, W
+
+
+def keypoints_flow_3d(kp, depth1, depth2, flow, K_inv, want_first: bool = False):
+    B, H, W = _check_maps(depth1, depth2, flow)
+    p, stride, N = _kp_args(kp, B)
+    p2 = torch.empty((B, N, 3), device=flow.device, dtype=torch.float64)
+    p1 = torch.empty_like(p2) if want_first else None
+    valid = torch.empty((B, N), device=flow.device, dtype=torch.uint8)
+    _lib.call("vo_keypoints_flow_3d", p, stride, _dev(depth1, "depth1", torch.float32),
+              _dev(depth2, "depth2", torch.float32), _dev(flow, "flow", torch.float32), _host9(K_inv),
+              p2.data_ptr(), valid.data_ptr(), 0 if p1 is None else p1.data_ptr(), B, N, H, W, _stream())
+    return (p2, valid.bool(), p1) if want_first else (p2, valid.bool())
+
+
+def pair_correspondences(kp, depth1, depth2, flow, K_inv, min_depth=0.0, max_depth=15.0, max_dz=1.0):
+    """Per-pair weighted correspondences -> P1, P2 (B,N,3) f64, weight (B,N) uint8,
+    n_in_range (B) int32."""
+    B, H, W = _check_maps(depth1, depth2, flow)
+    p, stride, N = _kp_args(kp, B)
+    dev = flow.device
+    p1 = torch.empty((B, N, 3), device=dev, dtype=torch.float64)
+    p2 = torch.empty_like(p1)
+    wgt = torch.empty((B, N), device=dev, dtype=torch.uint8)
+    n_in = torch.empty((B,), device=dev, dtype=torch.int32)
+    _lib.call("vo_pair_correspondences", p, stride, _dev(depth1, "depth1", torch.float32),
+              _dev(depth2, "depth2", torch.float32), _dev(flow, "flow", torch.float32), _host9(K_inv),
+              float(min_depth), float(max_depth), float(max_dz), p1.data_ptr(), p2.data_ptr(),
+              wgt.data_ptr(), n_in.data_ptr(), B, N, H, W, _stream())
+    return p1, p2, wgt, n_in
+
+
+def kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None, offset=None):
+    """(B,N,3) float64 point sets -> T (B,4,4) float64, n_used (B) int32."""
+    if P.dim() != 3 or P.shape[2] != 3 or Q.shape != P.shape:
+        raise ValueError("P and Q must both be (B,N,3)")
+    B, N, _ = P.shape
+    if weight is not None and tuple(weight.shape) != (B, N):
+        raise ValueError("weight must be (B,N)")
+    T = torch.empty((B, 4, 4), device=P.device, dtype=torch.float64)
+    n_used = torch.empty((B,), device=P.device, dtype=torch.int32)
+    off = None
+    if offset is not None:
+        o = np.asarray(offset, dtype=np.float64).reshape(-1)
+        if o.size != 3:
+            raise ValueError("offset must have 3 elements")
+        off = (ctypes.c_double * 3)(*o.tolist())
+    _lib.call("vo_kabsch_batch", _dev(P, "P", torch.float64), _dev(Q, "Q", torch.float64),
+              _opt(weight, "weight", torch.uint8), off, T.data_ptr(), n_used.data_ptr(), B, N, _stream())
+    return T, n_used

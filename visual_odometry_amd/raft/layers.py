@@ -1,0 +1,138 @@
+"""Convolutional encoders of RAFT and RAFT-Stereo (PyTorch-ROCm / MIOpen).
+
+These stay ordinary ``nn.Module`` stacks; only the correlation / lookup /
+upsampling operators around them are hand-written HIP.  Sub-module names follow
+the published RAFT / RAFT-Stereo models (``conv1``, ``norm1``, ``layer1``..,
+``conv2``, ``outputs08``..) so that a state dict trained with those models,
+``module.`` prefix stripped, loads unchanged; the reference builds them with
+``RAFT(args)`` / ``RAFTStereo(args)`` at flow/flow_map_RAFT.py:42 and
+stereo/stereo_disparity_RAFT.py:46.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+def _norm(kind: str, planes: int) -> nn.Module:
+    if kind == "group":
+        return nn.GroupNorm(num_groups=planes // 8, num_channels=planes)
+    if kind == "batch":
+        return nn.BatchNorm2d(planes)
+    if kind == "instance":
+        return nn.InstanceNorm2d(planes)
+    if kind == "none":
+        return nn.Sequential()
+    raise ValueError(f"unknown norm '{kind}'")
+
+
+class ResidualBlock(nn.Module):
+    """Two 3x3 convs with a (strided 1x1) skip; the skip conv exists whenever the
+    block changes resolution or width."""
+
+    def __init__(self, in_planes: int, planes: int, norm_fn: str = "group", stride: int = 1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1 = _norm(norm_fn, planes)
+        self.norm2 = _norm(norm_fn, planes)
+        if stride == 1 and in_planes == planes:
+            self.downsample = None
+        else:
+            self.norm3 = _norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+def _init_weights(module: nn.Module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 1)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+class BasicEncoder(nn.Module):
+    """Feature / context encoder: 7x7 stem then three residual stages (64, 96, 128)
+    and a 1x1 projection.  ``downsample`` = 3 gives 1/8 resolution (RAFT); 2 gives
+    1/4 (RAFT-Stereo with n_downsample=2: the stem runs at full resolution)."""
+
+    def __init__(self, output_dim: int = 128, norm_fn: str = "batch", downsample: int = 3):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.norm1 = _norm(norm_fn, 64)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1 + (downsample > 2), padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = 64
+        self.layer1 = self._make_layer(64, stride=1)
+        self.layer2 = self._make_layer(96, stride=1 + (downsample > 1))
+        self.layer3 = self._make_layer(128, stride=1 + (downsample > 0))
+        self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        _init_weights(self)
+
+    def _make_layer(self, dim: int, stride: int = 1) -> nn.Sequential:
+        blocks = nn.Sequential(ResidualBlock(self.in_planes, dim, self.norm_fn, stride=stride),
+                               ResidualBlock(dim, dim, self.norm_fn, stride=1))
+        self.in_planes = dim
+        return blocks
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        return self.conv2(x)
+
+
+class MultiBasicEncoder(nn.Module):
+    """RAFT-Stereo context encoder: the same trunk plus two more stride-2 stages,
+    with one (hidden, context) head pair per GRU resolution."""
+
+    def __init__(self, output_dim, norm_fn: str = "batch", downsample: int = 3):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.norm1 = _norm(norm_fn, 64)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=1 + (downsample > 2), padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = 64
+        self.layer1 = self._make_layer(64, stride=1)
+        self.layer2 = self._make_layer(96, stride=1 + (downsample > 1))
+        self.layer3 = self._make_layer(128, stride=1 + (downsample > 0))
+        self.layer4 = self._make_layer(128, stride=2)
+        self.layer5 = self._make_layer(128, stride=2)
+        self.outputs08 = nn.ModuleList([
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), nn.Conv2d(128, dim[2], 3, padding=1))
+            for dim in output_dim])
+        self.outputs16 = nn.ModuleList([
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, stride=1), nn.Conv2d(128, dim[1], 3, padding=1))
+            for dim in output_dim])
+        self.outputs32 = nn.ModuleList([nn.Conv2d(128, dim[0], 3, padding=1) for dim in output_dim])
+        _init_weights(self)
+
+    def _make_layer(self, dim: int, stride: int = 1) -> nn.Sequential:
+        blocks = nn.Sequential(ResidualBlock(self.in_planes, dim, self.norm_fn, stride=stride),
+                               ResidualBlock(dim, dim, self.norm_fn, stride=1))
+        self.in_planes = dim
+        return blocks
+
+    def forward(self, x: torch.Tensor, num_layers: int = 3):
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        out08 = [f(x) for f in self.outputs08]
+        if num_layers == 1:
+            return (out08,)
+        y = self.layer4(x)
+        out16 = [f(y) for f in self.outputs16]
+        if num_layers == 2:
+            return (out08, out16)
+        z = self.layer5(y)
+        out32 = [f(z) for f in self.outputs32]
+        return (out08, out16, out32)

@@ -1,0 +1,191 @@
+"""RAFT-Flow and RAFT-Stereo with the correlation path on hand-written HIP kernels.
+
+The conv encoders and GRUs are PyTorch modules (MIOpen); the all-pairs
+correlation volume, its pyramid, the per-iteration windowed lookup and the final
+convex upsampling go through the C ABI in ``visual_odometry_amd.ops`` and exist
+only on the GPU.  Both models are inference-only (``test_mode`` of the published
+models): they return the low-resolution field and the upsampled field of the
+LAST iteration, and evaluate the mask head on that iteration only.
+
+Argument sets: RAFT-Flow as flow/flow_map_RAFT.py:36-40 (full model, 4 levels,
+radius 4); RAFT-Stereo as stereo/stereo_disparity_RAFT.py:33-44, with
+``hidden_dims`` / ``n_gru_layers`` overridable for the "realtime" variant of
+stereo/raft_args_realtime.json:9,17.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .layers import BasicEncoder, MultiBasicEncoder
+from .update import BasicMultiUpdateBlock, BasicUpdateBlock
+
+
+def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device, dtype=torch.float32),
+                            torch.arange(wd, device=device, dtype=torch.float32), indexing="ij")
+    return torch.stack([xs, ys], dim=0)[None].repeat(batch, 1, 1, 1).contiguous()
+
+
+def normalize_image(img: torch.Tensor) -> torch.Tensor:
+    """0..255 -> -1..1, as both published models do on entry."""
+    return (2 * (img / 255.0) - 1.0).contiguous()
+
+
+def pixel_major(fmap: torch.Tensor) -> torch.Tensor:
+    """(B,D,H,W) -> (B,H,W,D) contiguous float32: the layout the correlation kernel
+    reads (each pixel's feature vector is one contiguous K-row)."""
+    return fmap.float().permute(0, 2, 3, 1).contiguous()
+
+
+def load_checkpoint(model: nn.Module, path: str, device) -> None:
+    """Load a state dict saved from ``nn.DataParallel(model)`` (keys prefixed with
+    ``module.``), which is how the published checkpoints are stored and why the
+    reference wraps its models before loading (flow/flow_map_RAFT.py:42-45)."""
+    state = torch.load(path, map_location=device, weights_only=True)
+    state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+    model.load_state_dict(state)
+
+
+# --------------------------------------------------------------------------- flow
+
+@dataclass
+class RAFTFlowConfig:
+    corr_levels: int = 4
+    corr_radius: int = 4
+    hidden_dim: int = 128
+    context_dim: int = 128
+
+
+class RAFTFlow(nn.Module):
+    """RAFT optical flow at 1/8 resolution, 8x convex upsampling."""
+
+    def __init__(self, cfg: Optional[RAFTFlowConfig] = None):
+        super().__init__()
+        self.cfg = cfg or RAFTFlowConfig()
+        c = self.cfg
+        self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=3)
+        self.cnet = BasicEncoder(output_dim=c.hidden_dim + c.context_dim, norm_fn="batch", downsample=3)
+        self.update_block = BasicUpdateBlock(c.corr_levels, c.corr_radius, hidden_dim=c.hidden_dim)
+
+    @torch.no_grad()
+    def features(self, images: torch.Tensor) -> torch.Tensor:
+        """Normalised images (B,3,H,W) -> pixel-major feature maps (B,H/8,W/8,256)."""
+        return pixel_major(self.fnet(images))
+
+    @torch.no_grad()
+    def forward(self, image1, image2, iters: int = 12, flow_init=None, fmap1=None, fmap2=None):
+        """image1/2: (B,3,H,W) float 0..255, H and W multiples of 8.  Precomputed
+        pixel-major feature maps may be passed so that consecutive pairs of a
+        sequence share the encoder pass of their common frame."""
+        c = self.cfg
+        image1 = normalize_image(image1)
+        if fmap1 is None or fmap2 is None:
+            image2 = normalize_image(image2)
+            both = self.features(torch.cat([image1, image2], dim=0))
+            fmap1, fmap2 = both[: image1.shape[0]], both[image1.shape[0]:]
+        B, H8, W8, _ = fmap1.shape
+
+        corr = ops.corr_volume_2d(fmap1, fmap2)
+        pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
+
+        net, inp = torch.split(self.cnet(image1), [c.hidden_dim, c.context_dim], dim=1)
+        net, inp = torch.tanh(net), torch.relu(inp)
+
+        coords0 = coords_grid(B, H8, W8, image1.device)
+        coords1 = coords0.clone()
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+        raw_mask = None
+        for it in range(iters):
+            window = ops.corr_lookup_2d(pyramid, coords1.contiguous(), c.corr_radius)
+            flow = coords1 - coords0
+            net, raw_mask, delta = self.update_block(net, inp, window, flow, want_mask=(it == iters - 1))
+            coords1 = coords1 + delta
+        flow_low = (coords1 - coords0).contiguous()
+        flow_up = ops.convex_upsample(flow_low, raw_mask.contiguous(), 8, mask_scale=0.25)
+        return flow_low, flow_up
+
+
+# ------------------------------------------------------------------------- stereo
+
+@dataclass
+class RAFTStereoConfig:
+    hidden_dims: List[int] = field(default_factory=lambda: [128, 128, 128])
+    n_gru_layers: int = 3
+    n_downsample: int = 2
+    corr_levels: int = 4
+    corr_radius: int = 4
+    context_norm: str = "batch"
+    slow_fast_gru: bool = False
+
+    @staticmethod
+    def realtime() -> "RAFTStereoConfig":
+        return RAFTStereoConfig(hidden_dims=[64, 64, 64], n_gru_layers=2)
+
+
+class RAFTStereo(nn.Module):
+    """RAFT-Stereo with the "reg" (materialised per-row volume) correlation."""
+
+    def __init__(self, cfg: Optional[RAFTStereoConfig] = None):
+        super().__init__()
+        self.cfg = cfg or RAFTStereoConfig()
+        c = self.cfg
+        context_dims = c.hidden_dims
+        self.cnet = MultiBasicEncoder(output_dim=[c.hidden_dims, context_dims], norm_fn=c.context_norm,
+                                      downsample=c.n_downsample)
+        self.update_block = BasicMultiUpdateBlock(c.hidden_dims, c.n_gru_layers, c.n_downsample,
+                                                  c.corr_levels, c.corr_radius)
+        self.context_zqr_convs = nn.ModuleList(
+            [nn.Conv2d(context_dims[i], c.hidden_dims[i] * 3, 3, padding=1) for i in range(c.n_gru_layers)])
+        self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=c.n_downsample)
+
+    @torch.no_grad()
+    def forward(self, image1, image2, iters: int = 12, flow_init=None):
+        """image1/2: (B,3,H,W) float 0..255, H and W multiples of 32.  Returns
+        (low-res x-flow field (B,2,h,w), upsampled disparity (B,1,H,W), negative
+        for a rectified left/right pair)."""
+        c = self.cfg
+        image1 = normalize_image(image1)
+        image2 = normalize_image(image2)
+        B = image1.shape[0]
+
+        cnet_list = self.cnet(image1, num_layers=c.n_gru_layers)
+        both = pixel_major(self.fnet(torch.cat([image1, image2], dim=0)))
+        fmap1, fmap2 = both[:B], both[B:]
+        net_list = [torch.tanh(x[0]) for x in cnet_list]
+        inp_list = [torch.relu(x[1]) for x in cnet_list]
+        # the GRUs' context terms do not change across iterations: convolve once
+        inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+                    for i, conv in zip(inp_list, self.context_zqr_convs)]
+
+        corr = ops.corr_volume_1d(fmap1, fmap2)
+        pyramid = ops.corr_pyramid_1d(corr, c.corr_levels)
+
+        _, _, h, w = net_list[0].shape
+        coords0 = coords_grid(B, h, w, image1.device)
+        coords1 = coords0.clone()
+        if flow_init is not None:
+            coords1 = coords1 + flow_init
+        raw_mask = None
+        for it in range(iters):
+            window = ops.corr_lookup_1d(pyramid, coords1.contiguous(), c.corr_radius)
+            flow = coords1 - coords0
+            if c.n_gru_layers == 3 and c.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+            if c.n_gru_layers >= 2 and c.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=c.n_gru_layers == 3, iter16=True,
+                                             iter08=False, update=False)
+            net_list, raw_mask, delta = self.update_block(net_list, inp_list, window, flow,
+                                                          iter32=c.n_gru_layers == 3, iter16=c.n_gru_layers >= 2,
+                                                          want_mask=(it == iters - 1))
+            delta = torch.cat([delta[:, :1], torch.zeros_like(delta[:, 1:])], dim=1)   # epipolar: no y motion
+            coords1 = coords1 + delta
+        flow_low = (coords1 - coords0).contiguous()
+        disparity = ops.convex_upsample(flow_low, raw_mask.contiguous(), 2 ** c.n_downsample, out_channels=1,
+                                        mask_scale=0.25)
+        return flow_low, disparity

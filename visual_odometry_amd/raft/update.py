@@ -1,0 +1,174 @@
+"""Recurrent update operators of RAFT and RAFT-Stereo (PyTorch-ROCm / MIOpen).
+
+Sub-module names follow the published models (``encoder.convc1``, ``gru.convz1``,
+``flow_head.conv1``, ``mask.0`` ...) so trained state dicts load unchanged.  The
+only departure in behaviour is an optimisation that cannot change the result:
+the up-sampling mask head is evaluated only when the caller asks for it (the
+last refinement iteration in inference), and it is returned UN-scaled -- the
+0.25 factor is folded into the HIP convex-upsampling kernel.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class FlowHead(nn.Module):
+    def __init__(self, input_dim: int = 128, hidden_dim: int = 256, output_dim: int = 2):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.conv2(self.relu(self.conv1(x)))
+
+
+class SepConvGRU(nn.Module):
+    """GRU with separable 1x5 then 5x1 gates (RAFT-Flow)."""
+
+    def __init__(self, hidden_dim: int = 128, input_dim: int = 192 + 128):
+        super().__init__()
+        cat = hidden_dim + input_dim
+        self.convz1 = nn.Conv2d(cat, hidden_dim, (1, 5), padding=(0, 2))
+        self.convr1 = nn.Conv2d(cat, hidden_dim, (1, 5), padding=(0, 2))
+        self.convq1 = nn.Conv2d(cat, hidden_dim, (1, 5), padding=(0, 2))
+        self.convz2 = nn.Conv2d(cat, hidden_dim, (5, 1), padding=(2, 0))
+        self.convr2 = nn.Conv2d(cat, hidden_dim, (5, 1), padding=(2, 0))
+        self.convq2 = nn.Conv2d(cat, hidden_dim, (5, 1), padding=(2, 0))
+
+    @staticmethod
+    def _step(h, x, convz, convr, convq):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(convz(hx))
+        r = torch.sigmoid(convr(hx))
+        q = torch.tanh(convq(torch.cat([r * h, x], dim=1)))
+        return (1 - z) * h + z * q
+
+    def forward(self, h, x):
+        h = self._step(h, x, self.convz1, self.convr1, self.convq1)
+        return self._step(h, x, self.convz2, self.convr2, self.convq2)
+
+
+class ConvGRU(nn.Module):
+    """3x3 GRU whose context contribution (cz, cr, cq) is precomputed once per
+    image (RAFT-Stereo)."""
+
+    def __init__(self, hidden_dim: int, input_dim: int, kernel_size: int = 3):
+        super().__init__()
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        x = torch.cat(x_list, dim=1)
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(self.convz(hx) + cz)
+        r = torch.sigmoid(self.convr(hx) + cr)
+        q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)) + cq)
+        return (1 - z) * h + z * q
+
+
+class FlowMotionEncoder(nn.Module):
+    """Correlation window + current flow -> 128 motion features (RAFT-Flow widths)."""
+
+    def __init__(self, cor_planes: int):
+        super().__init__()
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+    def forward(self, flow, corr):
+        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
+        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
+        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+        return torch.cat([out, flow], dim=1)
+
+
+class StereoMotionEncoder(nn.Module):
+    """Same structure with RAFT-Stereo's widths (64-channel branches)."""
+
+    def __init__(self, cor_planes: int):
+        super().__init__()
+        self.convc1 = nn.Conv2d(cor_planes, 64, 1, padding=0)
+        self.convc2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 64, 7, padding=3)
+        self.convf2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 64, 128 - 2, 3, padding=1)
+
+    def forward(self, flow, corr):
+        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
+        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
+        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+        return torch.cat([out, flow], dim=1)
+
+
+class BasicUpdateBlock(nn.Module):
+    """RAFT-Flow update: motion encoder -> SepConvGRU -> flow head (+ mask head)."""
+
+    def __init__(self, corr_levels: int = 4, corr_radius: int = 4, hidden_dim: int = 128):
+        super().__init__()
+        self.encoder = FlowMotionEncoder(corr_levels * (2 * corr_radius + 1) ** 2)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, 64 * 9, 1, padding=0))
+
+    def forward(self, net, inp, corr, flow, want_mask: bool = True):
+        motion = self.encoder(flow, corr)
+        net = self.gru(net, torch.cat([inp, motion], dim=1))
+        delta_flow = self.flow_head(net)
+        raw_mask = self.mask(net) if want_mask else None      # caller scales by 0.25
+        return net, raw_mask, delta_flow
+
+
+def pool2x(x):
+    return F.avg_pool2d(x, 3, stride=2, padding=1)
+
+
+def interp(x, dest):
+    return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
+
+
+class BasicMultiUpdateBlock(nn.Module):
+    """RAFT-Stereo update: up to three ConvGRUs at 1/32-1/16-1/8 of the working
+    resolution exchanging pooled / interpolated state, finest one fed by the
+    motion encoder."""
+
+    def __init__(self, hidden_dims, n_gru_layers: int, n_downsample: int, corr_levels: int = 4,
+                 corr_radius: int = 4):
+        super().__init__()
+        self.n_gru_layers = n_gru_layers
+        self.encoder = StereoMotionEncoder(corr_levels * (2 * corr_radius + 1))
+        encoder_output_dim = 128
+        self.gru08 = ConvGRU(hidden_dims[2], encoder_output_dim + hidden_dims[1] * (n_gru_layers > 1))
+        self.gru16 = ConvGRU(hidden_dims[1], hidden_dims[0] * (n_gru_layers == 3) + hidden_dims[2])
+        self.gru32 = ConvGRU(hidden_dims[0], hidden_dims[1])
+        self.flow_head = FlowHead(hidden_dims[2], hidden_dim=256, output_dim=2)
+        factor = 2 ** n_downsample
+        self.mask = nn.Sequential(nn.Conv2d(hidden_dims[2], 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, (factor ** 2) * 9, 1, padding=0))
+
+    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
+                want_mask: bool = True):
+        if iter32:
+            net[2] = self.gru32(net[2], *(inp[2]), pool2x(net[1]))
+        if iter16:
+            if self.n_gru_layers > 2:
+                net[1] = self.gru16(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+            else:
+                net[1] = self.gru16(net[1], *(inp[1]), pool2x(net[0]))
+        if iter08:
+            motion = self.encoder(flow, corr)
+            if self.n_gru_layers > 1:
+                net[0] = self.gru08(net[0], *(inp[0]), motion, interp(net[1], net[0]))
+            else:
+                net[0] = self.gru08(net[0], *(inp[0]), motion)
+        if not update:
+            return net
+        delta_flow = self.flow_head(net[0])
+        raw_mask = self.mask(net[0]) if want_mask else None   # caller scales by 0.25
+        return net, raw_mask, delta_flow
