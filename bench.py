@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""Headline benchmark: VO frame-pairs/s at 640x480 (RAFT-Stereo + RAFT-Flow + pose).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the whole hot path over one chunk of ``--batch`` consecutive
+synthetic stereo frame pairs that are already resident in HBM: RAFT-Stereo on the
+chunk's new frames, disparity->depth, RAFT-Flow on every consecutive pair, keypoint
+lift / flow-warp / filters, Kabsch pose per pair.  Each rank (one process per GPU)
+works on its own shard of the sequence; there is no data-path collective (the
+4x4 poses are gathered once per sequence, outside the per-chunk hot path), so
+scaling is weak and ``value`` is the sum over ranks.
+
+Prints ONE JSON line (rank 0).  Besides the driver's fields it carries
+  roofline      the dominant hand-written kernel: algorithmic bytes or FLOPs per
+                launch / its mean device time per launch, measured with events on the
+                launch stream inside the timed region
+  kernels       the same figures for every hand-written kernel
+  cpu_baseline  the CPU oracle (stock-PyTorch RAFT restatement + NumPy geometry with
+                the reference's per-point loop) timed on this box's host cores on a
+                bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256):
+    """Per-STEP algorithmic bytes / FLOPs and launch counts of every hand-written
+    kernel for B frame pairs (= B new stereo frames + B flow pairs)."""
+    h8, w8 = H // 8, W // 8
+    n = h8 * w8
+    h4, w4 = H // 4, W // 4
+    lv2 = [(h8 >> i) * (w8 >> i) for i in range(4)]
+    lv1 = [w4 >> i for i in range(4)]
+    f = 4  # bytes per float32
+    return {
+        "vo_corr_volume_2d": dict(launches=1, flops=2.0 * n * n * D * B, bytes=(2 * n * D + n * n) * f * B),
+        "vo_corr_volume_1d": dict(launches=1, flops=2.0 * h4 * w4 * w4 * D * B,
+                                  bytes=(2 * h4 * w4 * D + h4 * w4 * w4) * f * B),
+        "vo_corr_pyramid_2d": dict(launches=1, bytes=B * n * sum(lv2) * f),
+        "vo_corr_pyramid_1d": dict(launches=1, bytes=B * h4 * w4 * sum(lv1) * f),
+        # coords + window out + the (2r+2)^2 patch each pixel needs per level
+        "vo_corr_lookup_2d": dict(launches=iters, bytes=iters * B * n * (2 + 4 * 81 + 4 * 100) * f),
+        "vo_corr_lookup_1d": dict(launches=iters, bytes=iters * B * h4 * w4 * (2 + 4 * 9 + 4 * 10) * f),
+        "vo_convex_upsample": dict(launches=2, bytes=B * f * ((576 + 2) * n + 2 * H * W + (144 + 2) * h4 * w4 + H * W)),
+        "vo_disparity_to_depth": dict(launches=1, bytes=B * H * W * 2 * f),
+        "vo_pair_correspondences": dict(launches=1, bytes=B * n_kp * (16 + 8 + 8 + 48 + 1)),
+        "vo_kabsch_batch": dict(launches=1, bytes=B * (n_kp * 49 + 128)),
+    }
+
+
+def cpu_baseline(vo, left, right, iters, cores):
+    """Time the CPU oracle on ONE frame pair of the same workload (1 stereo frame +
+    1 flow pair + geometry), using ``cores`` host threads."""
+    from oracle import geometry_ref, raft_ref
+    torch.set_num_threads(cores)
+    flow_m = copy.deepcopy(vo.flow_solver.model).cpu().eval()
+    stereo_m = copy.deepcopy(vo.disparity_solver.model).cpu().eval()
+    rgb = lambda a: a.float()[:, None].expand(-1, 3, -1, -1).contiguous().cpu()
+    l, r = rgb(left[:2]), rgb(right[:2])
+    small = torch.rand(1, 3, 64, 96) * 255                       # thread-pool / allocator warm-up
+    raft_ref.raft_flow_forward(flow_m, small, small, 1)
+    raft_ref.raft_stereo_forward(stereo_m, small, small, 1)
+    K_inv = vo.pts_xform.K_inv
+    kp = vo.pts_src.get_keypoints(None, vo.cfg.max_keypoints)
+    t0 = time.perf_counter()
+    _, disp = raft_ref.raft_stereo_forward(stereo_m, l, r, iters)          # both frames (depth1, depth2)
+    t_stereo = (time.perf_counter() - t0) / 2                                # steady state: one new frame per pair
+    t1 = time.perf_counter()
+    _, flow = raft_ref.raft_flow_forward(flow_m, l[:1], l[1:2], iters)
+    t_flow = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    depth = [geometry_ref.disparity_to_depth(disp[i, 0].numpy(), vo._fxB, 1.0) for i in range(2)]
+    geometry_ref.pair_pose(kp, depth[0], depth[1], flow[0].numpy(), K_inv, loop=True)
+    t_geo = (time.perf_counter() - t2)
+    per_pair = t_stereo + t_flow + t_geo
+    return {"value": 1.0 / per_pair, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame pair 640x480, {iters} iters: RAFT-Stereo(realtime) {t_stereo:.2f}s + RAFT-Flow "
+                      f"{t_flow:.2f}s + geometry (per-point loop) {t_geo * 1e3:.1f}ms",
+            "seconds_per_pair": per_pair}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="frame pairs per step and per GPU")
+    ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--stereo", choices=["realtime", "full"], default="realtime")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from visual_odometry_amd import ops, synthetic as syn
+    from visual_odometry_amd.pipeline import VisualOdometry, VOConfig
+    from visual_odometry_amd.raft.models import RAFTStereoConfig
+
+    H, W, B = args.height, args.width, args.batch
+    cfg = VOConfig(iters=args.iters,
+                   stereo=RAFTStereoConfig.realtime() if args.stereo == "realtime" else RAFTStereoConfig(),
+                   camera_offset=syn.CAMERA_OFFSET)
+    vo = VisualOdometry(cfg, syn.left_K(W / 640.0), syn.focal_length_px() * (W / 640.0), syn.baseline(),
+                        np.ones((H, W), bool), seed=0)
+    n_kp = vo.keypoints.shape[0]
+
+    # synthetic chunk: B+1 consecutive stereo frames, different per rank, resident in HBM
+    left, right = syn.stereo_sequence(seed=100 + rank, frames=B + 1, h=H, w=W)
+    left = torch.from_numpy(left).cuda()
+    right = torch.from_numpy(right).cuda()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # untimed: first chunk of the shard (computes the halo frame's depth too), then W warm-up steps
+    _, _, cached = vo.process_chunk(left, right, None)
+    for _ in range(args.warmup):
+        vo.process_chunk(left, right, cached)
+
+    rec = {}
+    sync_all()
+    ops.set_recorder(rec)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T, skipped, _ = vo.process_chunk(left, right, cached)
+    torch.cuda.synchronize()
+    ops.set_recorder(None)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pairs = world * B * args.steps
+    value = pairs / elapsed
+
+    # per-kernel device time from the events recorded inside the timed region
+    work = algorithmic_work(B, H, W, args.iters, n_kp)
+    kernels = {}
+    for name, evs in rec.items():
+        ms = [s.elapsed_time(e) for (s, e) in evs]
+        w = work.get(name, {})
+        per_step_ms = sum(ms) / args.steps
+        entry = {"launches_per_step": len(ms) // args.steps, "avg_us": 1e3 * sum(ms) / len(ms),
+                 "ms_per_step": per_step_ms}
+        if "bytes" in w:
+            entry["alg_GB_per_launch"] = w["bytes"] / w["launches"] / 1e9
+            entry["GBps"] = w["bytes"] / (per_step_ms * 1e-3) / 1e9
+        if "flops" in w:
+            entry["TFLOPs"] = w["flops"] / (per_step_ms * 1e-3) / 1e12
+        kernels[name] = entry
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    d = kernels[dom]
+    if "TFLOPs" in d:
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": d["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": d["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_us": d["avg_us"], "hbm_GBps": d.get("GBps")}
+    else:
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
+    hand_ms = sum(k["ms_per_step"] for k in kernels.values())
+
+    if rank == 0:
+        out = {
+            "metric": "VO frame-pairs/sec at 640x480 (flow+stereo+pose)", "value": value, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RAFT-Flow + RAFT-Stereo({args.stereo} args) {W}x{H}, {args.iters} iters, "
+                                   f"{n_kp} grid keypoints, Kabsch pose; synthetic stereo frame pairs resident in HBM",
+                       "pairs_per_step_per_gpu": B, "pairs_timed": pairs, "iters": args.iters,
+                       "sharding": f"{world} rank(s), contiguous pair ranges, no data-path collective"},
+            "roofline": roofline,
+            "hand_kernels_ms_per_step": hand_ms,
+            "hand_kernels_share_of_step": hand_ms / (1e3 * elapsed / args.steps),
+            "kernels": kernels,
+            "skipped_pairs_last_step": int(skipped.sum().item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = args.cpu_cores or min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(vo, left, right, args.iters, cores)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

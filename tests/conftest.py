@@ -32,5 +32,6 @@ def vo():
 
 def rot_angle(Ra, Rb):
     """Geodesic angle between two rotation matrices, radians."""
-    c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
-    return float(np.arccos(np.clip(c, -1.0, 1.0)))
+    # chord length instead of arccos(trace): accurate down to 1e-16 for tiny angles
+    chord = np.linalg.norm(np.asarray(Ra) - np.asarray(Rb)) / (2.0 * np.sqrt(2.0))
+    return float(2.0 * np.arcsin(min(1.0, chord)))

@@ -164,10 +164,10 @@ def test_kabsch_cases_and_batch(vo):
     for b in (1, 2, 3, 5):
         Tb, _ = ops.kabsch_batch(torch.from_numpy(P[:b]).to(dev), torch.from_numpy(Q[:b]).to(dev))
         np.testing.assert_allclose(Tb.cpu().numpy(), g["batch_T"][:b], atol=1e-11)
-    # no points at all: NaN pose and n_used == 0, like the reference's mean of an empty set
+    # no points at all: n_used == 0 and a NaN translation (the reference's mean of an empty set is NaN)
     Tz, nz = ops.kabsch_batch(torch.from_numpy(P[:1]).to(dev), torch.from_numpy(Q[:1]).to(dev),
                               torch.zeros((1, P.shape[1]), dtype=torch.uint8, device=dev))
-    assert int(nz[0]) == 0 and bool(torch.isnan(Tz[0, :3]).all())
+    assert int(nz[0]) == 0 and bool(torch.isnan(Tz[0, :3, 3]).all())
 
 
 def test_rejects_cpu_tensors_and_bad_shapes(vo):

@@ -128,7 +128,7 @@ def _coords(B, H, W, seed, spread):
     return c
 
 
-@pytest.mark.parametrize("B,H,W,radius,levels", [(1, 12, 20, 4, 4), (2, 8, 16, 3, 3), (1, 60, 80, 4, 4)])
+@pytest.mark.parametrize("B,H,W,radius,levels", [(1, 16, 24, 4, 4), (2, 8, 16, 3, 3), (1, 60, 80, 4, 4)])
 def test_lookup_2d(vo, B, H, W, radius, levels):
     from visual_odometry_amd import ops
     N = H * W

@@ -181,7 +181,7 @@ Mat3 load_mat3(const double* host9) {
 }
 
 int check_points_args(const char* fn, const void* kp, int batch, int N, int H, int W) {
-    if (!kp) return vo_fail(VO_ERR_INVALID_ARG, "%s: kp is null", fn);
+    if (!kp && N > 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: kp is null", fn);
     if (batch <= 0 || batch > 65535) return vo_fail(VO_ERR_INVALID_ARG, "%s: batch=%d outside [1,65535]", fn, batch);
     if (N < 0 || H <= 0 || W <= 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes N=%d H=%d W=%d", fn, N, H, W);
     return VO_OK;
@@ -191,9 +191,9 @@ int check_points_args(const char* fn, const void* kp, int batch, int N, int H, i
 
 extern "C" int vo_disparity_to_depth(const float* disparity, float* depth, int64_t n, double fxB,
                                      int divide_in_f64, void* stream) {
-    VO_REQUIRE(disparity && depth, "vo_disparity_to_depth: null pointer");
     VO_REQUIRE(n >= 0, "vo_disparity_to_depth: n=%lld < 0", (long long)n);
-    if (n == 0) return VO_OK;
+    if (n == 0) return VO_OK;                       // an empty map has no storage to point at
+    VO_REQUIRE(disparity && depth, "vo_disparity_to_depth: null pointer");
     int64_t blocks = vo_ceil_div(vo_ceil_div(n, 4), 256);
     if (blocks > 2048) blocks = 2048;               // grid-stride beyond 8 blocks per CU
     if (divide_in_f64)
@@ -209,8 +209,8 @@ extern "C" int vo_keypoints_to_3d(const double* kp, int64_t kp_batch_stride, con
                                   int W, void* stream) {
     int rc = check_points_args("vo_keypoints_to_3d", kp, batch, N, H, W);
     if (rc) return rc;
-    VO_REQUIRE(depth && Kinv_host && points_out, "vo_keypoints_to_3d: null pointer");
     if (N == 0) return VO_OK;
+    VO_REQUIRE(depth && Kinv_host && points_out, "vo_keypoints_to_3d: null pointer");
     dim3 grid((unsigned)vo_ceil_div(N, 256), (unsigned)batch);
     to3d_kernel<<<grid, dim3(256), 0, vo_stream(stream)>>>(kp, kp_batch_stride, depth, load_mat3(Kinv_host),
                                                           points_out, N, H, W);
@@ -223,8 +223,8 @@ extern "C" int vo_keypoints_flow_2d(const double* kp, int64_t kp_batch_stride, c
                                     void* stream) {
     int rc = check_points_args("vo_keypoints_flow_2d", kp, batch, N, H, W);
     if (rc) return rc;
-    VO_REQUIRE(flow && next_out && valid_out, "vo_keypoints_flow_2d: null pointer");
     if (N == 0) return VO_OK;
+    VO_REQUIRE(flow && next_out && valid_out, "vo_keypoints_flow_2d: null pointer");
     dim3 grid((unsigned)vo_ceil_div(N, 256), (unsigned)batch);
     flow2d_kernel<<<grid, dim3(256), 0, vo_stream(stream)>>>(kp, kp_batch_stride, flow, next_out, valid_out, N, H, W);
     VO_CHECK_LAUNCH("vo_keypoints_flow_2d");
@@ -237,8 +237,8 @@ extern "C" int vo_keypoints_flow_3d(const double* kp, int64_t kp_batch_stride, c
                                     int H, int W, void* stream) {
     int rc = check_points_args("vo_keypoints_flow_3d", kp, batch, N, H, W);
     if (rc) return rc;
-    VO_REQUIRE(depth1 && depth2 && flow && Kinv_host && p2_out && valid_out, "vo_keypoints_flow_3d: null pointer");
     if (N == 0) return VO_OK;
+    VO_REQUIRE(depth1 && depth2 && flow && Kinv_host && p2_out && valid_out, "vo_keypoints_flow_3d: null pointer");
     dim3 grid((unsigned)vo_ceil_div(N, 256), (unsigned)batch);
     flow3d_kernel<0><<<grid, dim3(256), 0, vo_stream(stream)>>>(kp, kp_batch_stride, depth1, depth2, flow,
                                                                load_mat3(Kinv_host), 0.0, 0.0, 0.0, p1_out,
@@ -254,7 +254,8 @@ extern "C" int vo_pair_correspondences(const double* kp, int64_t kp_batch_stride
                                        int batch, int N, int H, int W, void* stream) {
     int rc = check_points_args("vo_pair_correspondences", kp, batch, N, H, W);
     if (rc) return rc;
-    VO_REQUIRE(depth1 && depth2 && flow && Kinv_host && p1_out && p2_out && weight_out && n_in_range_out,
+    VO_REQUIRE(n_in_range_out, "vo_pair_correspondences: n_in_range_out is null");
+    VO_REQUIRE(N == 0 || (depth1 && depth2 && flow && Kinv_host && p1_out && p2_out && weight_out),
                "vo_pair_correspondences: null pointer");
     hipError_t e = hipMemsetAsync(n_in_range_out, 0, sizeof(int32_t) * (size_t)batch, vo_stream(stream));
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "vo_pair_correspondences: memset: %s", hipGetErrorString(e));

@@ -23,6 +23,32 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing: while a recorder dict is installed, every C-ABI call
+# is bracketed by two events recorded on the stream the kernel is launched on, so
+# a caller can read each kernel's device-side duration after synchronising.
+_recorder = None
+
+
+def set_recorder(rec):
+    """Install (dict) or remove (None) the launch recorder; returns the old one.
+    The dict maps entry-point name -> list of (start_event, end_event, *sizes)."""
+    global _recorder
+    old, _recorder = _recorder, rec
+    return old
+
+
+def _call(name: str, *args) -> None:
+    if _recorder is None:
+        _lib.call(name, *args)
+        return
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    _lib.call(name, *args)
+    end.record()
+    _recorder.setdefault(name, []).append((start, end))
+
+
 def _dev(t: torch.Tensor, name: str, dtype: torch.dtype) -> int:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise ValueError(f"{name}: expected a GPU tensor (the HIP backend has no CPU path)")
@@ -60,7 +86,7 @@ def corr_volume_2d(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
     if fmap2.shape != fmap1.shape:
         raise ValueError("fmap1 and fmap2 must have the same shape")
     corr = torch.empty((B, H * W, H, W), device=fmap1.device, dtype=torch.float32)
-    _lib.call("vo_corr_volume_2d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+    _call("vo_corr_volume_2d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
               corr.data_ptr(), B, H, W, D, _stream())
     return corr
 
@@ -72,7 +98,7 @@ def corr_volume_1d(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
         raise ValueError("fmap2 must be (B,H,W2,D) matching fmap1")
     W2 = fmap2.shape[2]
     corr = torch.empty((B, H, W1, W2), device=fmap1.device, dtype=torch.float32)
-    _lib.call("vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+    _call("vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
               corr.data_ptr(), B, H, W1, W2, D, _stream())
     return corr
 
@@ -86,7 +112,7 @@ def corr_pyramid_2d(corr: torch.Tensor, levels: int = MAX_LEVELS):
     pyr = [corr] + [torch.empty((B, N, h, w), device=corr.device, dtype=torch.float32) for h, w in shapes[1:]]
     ptrs = [p.data_ptr() for p in pyr[1:]] + [0] * (MAX_LEVELS - levels)
     if levels > 1:
-        _lib.call("vo_corr_pyramid_2d", _dev(corr, "corr", torch.float32), *ptrs, B * N, H2, W2, _stream())
+        _call("vo_corr_pyramid_2d", _dev(corr, "corr", torch.float32), *ptrs, B * N, H2, W2, _stream())
     return pyr
 
 
@@ -101,7 +127,7 @@ def corr_pyramid_1d(corr: torch.Tensor, levels: int = MAX_LEVELS):
     pyr = [corr] + [torch.empty((B, H, W1, w), device=corr.device, dtype=torch.float32) for w in widths[1:]]
     ptrs = [p.data_ptr() for p in pyr[1:]] + [0] * (MAX_LEVELS - levels)
     if levels > 1:
-        _lib.call("vo_corr_pyramid_1d", _dev(corr, "corr", torch.float32), *ptrs, B * H * W1, W2, _stream())
+        _call("vo_corr_pyramid_1d", _dev(corr, "corr", torch.float32), *ptrs, B * H * W1, W2, _stream())
     return pyr
 
 
@@ -126,7 +152,7 @@ def corr_lookup_2d(pyr, coords: torch.Tensor, radius: int = 4, out: torch.Tensor
         out = torch.empty((B, ch, H, W), device=coords.device, dtype=torch.float32)
     elif tuple(out.shape) != (B, ch, H, W):
         raise ValueError("out has the wrong shape")
-    _lib.call("vo_corr_lookup_2d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
+    _call("vo_corr_lookup_2d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
               _dev(out, "out", torch.float32), B, H, W, H2, W2, len(pyr), radius, _stream())
     return out
 
@@ -147,7 +173,7 @@ def corr_lookup_1d(pyr, coords: torch.Tensor, radius: int = 4, out: torch.Tensor
         out = torch.empty((B, ch, H, W), device=coords.device, dtype=torch.float32)
     elif tuple(out.shape) != (B, ch, H, W):
         raise ValueError("out has the wrong shape")
-    _lib.call("vo_corr_lookup_1d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
+    _call("vo_corr_lookup_1d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
               _dev(out, "out", torch.float32), B, H, W, W2, len(pyr), radius, _stream())
     return out
 
@@ -162,7 +188,7 @@ def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, factor: int, out_cha
     if not 1 <= Cout <= Cf:
         raise ValueError("out_channels must be in 1..flow channels")
     out = torch.empty((B, Cout, factor * H, factor * W), device=flow.device, dtype=torch.float32)
-    _lib.call("vo_convex_upsample", _dev(flow, "flow", torch.float32), _dev(mask, "mask", torch.float32),
+    _call("vo_convex_upsample", _dev(flow, "flow", torch.float32), _dev(mask, "mask", torch.float32),
               out.data_ptr(), B, Cf, Cout, H, W, factor, float(mask_scale), _stream())
     return out
 
@@ -171,7 +197,7 @@ def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, factor: int, out_cha
 
 def disparity_to_depth(disparity: torch.Tensor, fxB: float, divide_in_f64: bool = True) -> torch.Tensor:
     depth = torch.empty_like(disparity)
-    _lib.call("vo_disparity_to_depth", _dev(disparity, "disparity", torch.float32), depth.data_ptr(),
+    _call("vo_disparity_to_depth", _dev(disparity, "disparity", torch.float32), depth.data_ptr(),
               disparity.numel(), float(fxB), int(bool(divide_in_f64)), _stream())
     return depth
 
@@ -193,7 +219,7 @@ def keypoints_to_3d(kp: torch.Tensor, depth: torch.Tensor, K_inv) -> torch.Tenso
     B, H, W = depth.shape
     p, stride, N = _kp_args(kp, B)
     out = torch.empty((B, N, 3), device=depth.device, dtype=torch.float64)
-    _lib.call("vo_keypoints_to_3d", p, stride, _dev(depth, "depth", torch.float32), _host9(K_inv),
+    _call("vo_keypoints_to_3d", p, stride, _dev(depth, "depth", torch.float32), _host9(K_inv),
               out.data_ptr(), B, N, H, W, _stream())
     return out
 
@@ -206,7 +232,7 @@ def keypoints_flow_2d(kp: torch.Tensor, flow: torch.Tensor):
     p, stride, N = _kp_args(kp, B)
     nxt = torch.empty((B, N, 2), device=flow.device, dtype=torch.float64)
     valid = torch.empty((B, N), device=flow.device, dtype=torch.uint8)
-    _lib.call("vo_keypoints_flow_2d", p, stride, _dev(flow, "flow", torch.float32), nxt.data_ptr(),
+    _call("vo_keypoints_flow_2d", p, stride, _dev(flow, "flow", torch.float32), nxt.data_ptr(),
               valid.data_ptr(), B, N, H, W, _stream())
     return nxt, valid.bool()
 
@@ -226,7 +252,7 @@ def keypoints_flow_3d(kp, depth1, depth2, flow, K_inv, want_first: bool = False)
     p2 = torch.empty((B, N, 3), device=flow.device, dtype=torch.float64)
     p1 = torch.empty_like(p2) if want_first else None
     valid = torch.empty((B, N), device=flow.device, dtype=torch.uint8)
-    _lib.call("vo_keypoints_flow_3d", p, stride, _dev(depth1, "depth1", torch.float32),
+    _call("vo_keypoints_flow_3d", p, stride, _dev(depth1, "depth1", torch.float32),
               _dev(depth2, "depth2", torch.float32), _dev(flow, "flow", torch.float32), _host9(K_inv),
               p2.data_ptr(), valid.data_ptr(), 0 if p1 is None else p1.data_ptr(), B, N, H, W, _stream())
     return (p2, valid.bool(), p1) if want_first else (p2, valid.bool())
@@ -242,7 +268,7 @@ def pair_correspondences(kp, depth1, depth2, flow, K_inv, min_depth=0.0, max_dep
     p2 = torch.empty_like(p1)
     wgt = torch.empty((B, N), device=dev, dtype=torch.uint8)
     n_in = torch.empty((B,), device=dev, dtype=torch.int32)
-    _lib.call("vo_pair_correspondences", p, stride, _dev(depth1, "depth1", torch.float32),
+    _call("vo_pair_correspondences", p, stride, _dev(depth1, "depth1", torch.float32),
               _dev(depth2, "depth2", torch.float32), _dev(flow, "flow", torch.float32), _host9(K_inv),
               float(min_depth), float(max_depth), float(max_dz), p1.data_ptr(), p2.data_ptr(),
               wgt.data_ptr(), n_in.data_ptr(), B, N, H, W, _stream())
@@ -264,6 +290,6 @@ def kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None =
         if o.size != 3:
             raise ValueError("offset must have 3 elements")
         off = (ctypes.c_double * 3)(*o.tolist())
-    _lib.call("vo_kabsch_batch", _dev(P, "P", torch.float64), _dev(Q, "Q", torch.float64),
+    _call("vo_kabsch_batch", _dev(P, "P", torch.float64), _dev(Q, "Q", torch.float64),
               _opt(weight, "weight", torch.uint8), off, T.data_ptr(), n_used.data_ptr(), B, N, _stream())
     return T, n_used

@@ -1,0 +1,179 @@
+"""Batched stereo visual-odometry loop on one GPU, and its sharding over ranks.
+
+This is the reference's tracking loop (test_camera_tracking.py:116-214) turned
+inside out: instead of one frame pair per Python iteration with two host/device
+round trips, a CHUNK of consecutive frames stays in HBM and every stage runs
+once per chunk:
+
+    RAFT-Stereo on each new frame      -> disparity   (:165)
+    depth = fx*B/|d|                   -> depth maps  (:166)  one frame's depth is
+                                           reused as depth1 of the next pair (:149-150)
+    RAFT-Flow on each consecutive pair -> flow        (:168)  the feature encoder runs
+                                           once per FRAME, not twice per pair
+    grid keypoints, lift, flow-warp, filters -> weighted correspondences (:176-200)
+    Kabsch per pair                    -> T_rel 4x4   (:204-207)
+
+Pairs are independent given the frames, so a sequence is sharded contiguously
+over ranks (one process per GPU) with a one-frame halo; the only exchange is an
+all-gather of the 4x4 relative poses, composed on the host in float64 (:210).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .geometry import HipCameraSvdXform, HipKeypoints3DFlow, HipKeypoints3DXform, HipStereoDepth, UniformKeyPoints
+from .raft.models import RAFTStereoConfig, normalize_image
+from .raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT, gray_batch_to_rgb
+
+
+@dataclass
+class VOConfig:
+    iters: int = 12                       # refinement iterations of both networks
+    stereo: RAFTStereoConfig = field(default_factory=RAFTStereoConfig)
+    max_keypoints: int = 320              # test_camera_tracking.py:176
+    min_depth: float = 0.0                # :57
+    max_depth: float = 15.0               # :58
+    max_dz: float = 1.0                   # :198
+    min_points: int = 4                   # :188
+    camera_offset: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+
+
+class _Rig:
+    """Minimal camera/stereo parameter holders for the plugin constructors."""
+
+    def __init__(self, K):
+        self.K = np.asarray(K, dtype=np.float64)
+
+
+class VisualOdometry:
+    """All per-frame stages of the tracking loop on the current GPU."""
+
+    def __init__(self, cfg: VOConfig, K: np.ndarray, focal_length_px, baseline, mask: np.ndarray,
+                 flow_checkpoint: Optional[str] = None, stereo_checkpoint: Optional[str] = None, seed: int = 0):
+        self.cfg = cfg
+        self.flow_solver = HipOpticalFlowRAFT(flow_checkpoint, None, cfg.iters, seed=seed)
+        self.disparity_solver = HipDisparityRAFT(stereo_checkpoint, None, cfg.iters, config=cfg.stereo, seed=seed + 1)
+        self.device = self.flow_solver.device
+        self._fxB = focal_length_px * baseline
+        self._f64 = isinstance(self._fxB, np.float64)
+        cam = _Rig(K)
+        self.pts_src = UniformKeyPoints(mask)
+        self.pts_xform = HipKeypoints3DXform(cam)
+        self.pts_flow = HipKeypoints3DFlow(cam, self.pts_xform, mask)
+        self.cam_estimator = HipCameraSvdXform(np.array(cfg.camera_offset))
+        self.keypoints = self.pts_src.get_keypoints_device(cfg.max_keypoints)
+
+    # -- stages ------------------------------------------------------------
+    def depth_maps(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
+        """(F,H,W) gray GPU frames -> (F,H,W) float32 depth."""
+        disp = self.disparity_solver.compute_disparity_batch(gray_batch_to_rgb(left), gray_batch_to_rgb(right))
+        return ops.disparity_to_depth(disp, float(self._fxB), self._f64)
+
+    def flows(self, left: torch.Tensor) -> torch.Tensor:
+        """(F,H,W) gray GPU frames -> (F-1,2,H,W) flow between consecutive frames."""
+        rgb = gray_batch_to_rgb(left)
+        h, w = rgb.shape[-2:]
+        if h % 8 == 0 and w % 8 == 0:      # no padding: share one encoder pass per frame
+            fm = self.flow_solver.model.features(normalize_image(rgb))
+            return self.flow_solver.compute_flow_batch(rgb[:-1], rgb[1:], fmap1=fm[:-1], fmap2=fm[1:])
+        return self.flow_solver.compute_flow_batch(rgb[:-1].contiguous(), rgb[1:].contiguous())
+
+    def poses(self, depth: torch.Tensor, flow: torch.Tensor):
+        """(F,H,W) depth + (F-1,2,H,W) flow -> T_rel (F-1,4,4) f64, skipped (F-1) bool."""
+        c = self.cfg
+        P1, P2, wgt, n_in = self.pts_flow.pair_correspondences_batch(
+            self.keypoints, depth[:-1], depth[1:], flow, c.min_depth, c.max_depth, c.max_dz)
+        T, n_used = self.cam_estimator.compute_camera_xform_batch(P1, P2, wgt)
+        # the reference skips a pair when fewer than 4 points survive the range filter;
+        # a pair whose final selection is empty has no pose at all (NaN) and is skipped too
+        skipped = (n_in < c.min_points) | (n_used < 1)
+        return T, skipped
+
+    # -- chunk / sequence --------------------------------------------------
+    @torch.no_grad()
+    def process_chunk(self, left: torch.Tensor, right: torch.Tensor, first_depth: Optional[torch.Tensor] = None):
+        """F consecutive frames -> (T_rel (F-1,4,4), skipped (F-1), depth of the last
+        frame).  ``first_depth`` is the cached depth of frame 0 (the previous chunk's
+        last frame); without it frame 0's stereo pair is evaluated too."""
+        if left.shape[0] < 2:
+            raise ValueError("a chunk needs at least two frames")
+        if first_depth is None:
+            depth = self.depth_maps(left, right)
+        else:
+            depth = torch.cat([first_depth[None], self.depth_maps(left[1:], right[1:])], dim=0)
+        flow = self.flows(left)
+        T, skipped = self.poses(depth, flow)
+        return T, skipped, depth[-1]
+
+    @torch.no_grad()
+    def run(self, left: torch.Tensor, right: torch.Tensor, chunk_pairs: int = 8):
+        """Whole (F,H,W) uint8 GPU sequence -> (T_rel (F-1,4,4), skipped (F-1)) on the GPU."""
+        F = left.shape[0]
+        Ts, sk, cached = [], [], None
+        for s in range(0, F - 1, chunk_pairs):
+            e = min(s + chunk_pairs, F - 1)
+            T, k, cached = self.process_chunk(left[s:e + 1], right[s:e + 1], cached)
+            Ts.append(T); sk.append(k)
+        return torch.cat(Ts), torch.cat(sk)
+
+
+# ------------------------------------------------------------------ sharding
+
+def shard_pairs(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [start, end) of pair indices for ``rank``; blocks have
+    ceil(n/world) pairs, the tail ranks may get fewer (or none).  Rank r needs
+    frames start..end inclusive (one halo frame)."""
+    per = -(-n_pairs // world)
+    start = min(rank * per, n_pairs)
+    return start, min(start + per, n_pairs)
+
+
+def gather_poses(T_local: torch.Tensor, skipped_local: torch.Tensor, n_pairs: int, group=None):
+    """All-gather the per-rank (k,4,4) float64 relative poses and skip flags into
+    the full (n_pairs,4,4) / (n_pairs,) arrays on the host, in pair order.  Blocks
+    are padded to ceil(n/world) so one equal-sized all_gather suffices (RCCL over
+    xGMI with the nccl backend; gloo works the same for CPU tensors)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return T_local.cpu().numpy(), skipped_local.cpu().numpy().astype(bool)
+    world = dist.get_world_size(group)
+    per = -(-n_pairs // world)
+    payload = torch.zeros((per, 17), dtype=torch.float64, device=T_local.device)
+    k = T_local.shape[0]
+    payload[:k, :16] = T_local.reshape(k, 16)
+    payload[:k, 16] = skipped_local.to(torch.float64)
+    payload[k:, 16] = 1.0                                   # padding rows count as skipped
+    out = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(out, payload, group=group)
+    full = torch.cat(out)[:n_pairs].cpu().numpy()
+    return full[:, :16].reshape(-1, 4, 4).copy(), full[:, 16] > 0.5
+
+
+def compose_trajectory(T_rel: np.ndarray, skipped: Optional[np.ndarray] = None) -> np.ndarray:
+    """T_global <- T_global @ T_rel in float64, in pair order (the product is not
+    commutative); skipped pairs leave the pose unchanged
+    (test_camera_tracking.py:107,188-190,210).  Returns (n,4,4) global poses."""
+    T_rel = np.asarray(T_rel, dtype=np.float64).reshape(-1, 4, 4)
+    out = np.empty_like(T_rel)
+    G = np.eye(4)
+    for i in range(T_rel.shape[0]):
+        if skipped is None or not skipped[i]:
+            G = G @ T_rel[i]
+        out[i] = G
+    return out
+
+
+def write_trajectory(path: str, T_rel: np.ndarray, skipped: Optional[np.ndarray] = None) -> None:
+    """The reference's text format: header, then ``i, [t], [R row-major]`` per
+    non-skipped pair (test_camera_tracking.py:105,213-214)."""
+    with open(path, "w") as f:
+        f.write("frame, translation, rotation_matrix_flat\n")
+        for i, T in enumerate(np.asarray(T_rel).reshape(-1, 4, 4)):
+            if skipped is not None and skipped[i]:
+                continue
+            f.write(f"{i}, {T[:3, 3].tolist()}, {T[:3, :3].flatten().tolist()}\n")
