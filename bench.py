@@ -65,6 +65,26 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
     }
 
 
+PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_pyramid_2d": "pyr2d", "vo_corr_lookup_2d": "lookup2d",
+            "vo_corr_lookup_1d": "lookup1d"}
+
+
+def pmc_traffic(kernel: str, B: int, H: int, W: int):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE
+    and WRITE_SIZE collected separately; FETCH_SIZE doubled per the gfx950 correction
+    for wide reads), or None when no pass exists for this kernel and shape."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path) or kernel not in PMC_KEYS:
+        return None
+    meta = json.load(open(path))
+    if (meta.get("batch_pairs"), meta.get("height"), meta.get("width")) != (B, H, W):
+        return None
+    k = meta["kernels"].get(PMC_KEYS[kernel])
+    if not k:
+        return None
+    return (2.0 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
+
+
 def cpu_baseline(vo, left, right, iters, cores):
     """Time the CPU oracle on ONE frame pair of the same workload (1 stereo frame +
     1 flow pair + geometry), using ``cores`` host threads."""
@@ -191,6 +211,8 @@ def main():
     else:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
+    roofline["traffic"] = pmc_traffic(dom, B, H, W)
+    roofline["alg_per_launch"] = (work[dom].get("flops") if roofline["bound"] == "mfma" else work[dom]["bytes"]) / work[dom]["launches"]
     hand_ms = sum(k["ms_per_step"] for k in kernels.values())
 
     if rank == 0:

@@ -51,10 +51,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
     float* As = smem;                                   // [2][BM][LDS_STRIDE]
     float* Bs = smem + 2 * BM * LDS_STRIDE;             // [2][BN][LDS_STRIDE]
 
+    // Work order inside one matrix: row-tiles are taken in groups of GROUP_M and a
+    // group sweeps the column-tiles with the row-tile index fastest, so the ~64
+    // workgroups resident on an XCD share GROUP_M A-tiles and ~8 B-tiles (about 2 MB,
+    // inside the 4 MB L2) instead of streaming all of B once per row-tile.
+    constexpr int GROUP_M = 8;       // measured: 1 -> 893 us, 4 -> 877, 8 -> 870, 16 -> 903 (8 pairs of 640x480)
     const unsigned work = xcd_remap(blockIdx.x, nwg);
-    const int tn = work % tiles_n;
-    const int tm = (work / tiles_n) % tiles_m;
-    const int g = work / (tiles_n * tiles_m);
+    const unsigned per_g = (unsigned)tiles_n * tiles_m;
+    const int g = work / per_g;
+    const unsigned w_in = work - g * per_g;
+    const unsigned group_sz = GROUP_M * tiles_n;
+    const unsigned grp = w_in / group_sz;
+    const int rows_in_grp = min(GROUP_M, tiles_m - (int)grp * GROUP_M);
+    const unsigned w_grp = w_in - grp * group_sz;
+    const int tm = grp * GROUP_M + w_grp % rows_in_grp;
+    const int tn = w_grp / rows_in_grp;
     const float* Ag = A + g * strideA;
     const float* Bg = B + g * strideB;
     float* Cg = C + g * strideC;

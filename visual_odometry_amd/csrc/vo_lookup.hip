@@ -72,15 +72,20 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int xs, 
     }
 }
 
-template <int R>
+// RPT = window rows (y offsets) per lane.  RPT = 2r+1 gives one lane per (pair,
+// level, pixel); smaller RPT splits a pixel's window over (2r+1)/RPT lanes, which
+// re-reads the shared patch rows from L1 but multiplies the waves in flight.
+template <int R, int RPT>
 __global__ __launch_bounds__(256) void lookup2d_kernel(Levels lv, const float* __restrict__ coords,
                                                        float* __restrict__ out, int64_t total, int HW, int levels) {
-    constexpr int WIN = 2 * R + 1, T = 2 * R + 2;
+    constexpr int WIN = 2 * R + 1, T = 2 * R + 2, PARTS = WIN / RPT;
+    static_assert(WIN % RPT == 0, "rows per lane must divide the window");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int p = (int)(t % HW);
-    const int l = (int)((t / HW) % levels);
-    const int64_t b = t / ((int64_t)HW * levels);
+    const int part = (int)((t / HW) % PARTS);
+    const int l = (int)((t / ((int64_t)HW * PARTS)) % levels);
+    const int64_t b = t / ((int64_t)HW * PARTS * levels);
 
     const float inv = 1.0f / (float)(1 << l);                       // exact power of two
     float fx, fy;
@@ -93,14 +98,16 @@ __global__ __launch_bounds__(256) void lookup2d_kernel(Levels lv, const float* _
     float* o = out + (b * levels + l) * (int64_t)(WIN * WIN) * HW + p;
 
     const float wx1 = fx, wx0 = 1.0f - fx, wy1 = fy, wy0 = 1.0f - fy;
+    const int j0 = part * RPT;
     float prev[WIN], cur[WIN], v[T];
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
+    for (int jj = 0; jj <= RPT; ++jj) {
+        const int j = j0 + jj;
         const int y = y0 - R + j;
         load_row<R>(img + (int64_t)y * w, x0 - R, w, y >= 0 && y < h, v);
 #pragma unroll
         for (int a = 0; a < WIN; ++a) cur[a] = wx0 * v[a] + wx1 * v[a + 1];
-        if (j > 0) {
+        if (jj > 0) {
             // window row j-1 is the y-offset index; the x-offset index a is the slow
             // channel index: channel = a*(2r+1) + (j-1)
 #pragma unroll
@@ -165,13 +172,18 @@ extern "C" int vo_corr_lookup_2d(const float* l0, const float* l1, const float* 
     }
     VO_REQUIRE(lv.h[levels - 1] > 0 && lv.w[levels - 1] > 0, "vo_corr_lookup_2d: level %d is empty", levels - 1);
     const int HW = H * W;
+    // One lane per (pair, level, pixel).  Splitting a window over 3 or 9 lanes was
+    // measured slower (58 / 70 us against 52 us at 8 pairs of 640x480): the kernel is
+    // bound by the cache lines it pulls in, and split lanes pull shared rows twice.
     const int64_t total = (int64_t)batch * levels * HW;
     const int64_t blocks = vo_ceil_div(total, 256);
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_corr_lookup_2d: grid too large");
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = vo_stream(stream);
     if (radius == 4)
-        lookup2d_kernel<4><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, total, HW, levels);
+        lookup2d_kernel<4, 9><<<grid, block, 0, st>>>(lv, coords, out, total, HW, levels);
     else
-        lookup2d_kernel<3><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, total, HW, levels);
+        lookup2d_kernel<3, 7><<<grid, block, 0, st>>>(lv, coords, out, total, HW, levels);
     VO_CHECK_LAUNCH("vo_corr_lookup_2d");
     return VO_OK;
 }
