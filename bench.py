@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--stereo", choices=["realtime", "full"], default="realtime")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="let MIOpen benchmark its solvers per conv shape")
+    ap.add_argument("--channels-last", action="store_true", help="run the conv nets in NHWC memory format")
     ap.add_argument("--cpu-cores", type=int, default=0)
     args = ap.parse_args()
 
@@ -146,12 +148,16 @@ def main():
     from visual_odometry_amd.raft.models import RAFTStereoConfig
 
     H, W, B = args.height, args.width, args.batch
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     cfg = VOConfig(iters=args.iters,
                    stereo=RAFTStereoConfig.realtime() if args.stereo == "realtime" else RAFTStereoConfig(),
                    camera_offset=syn.CAMERA_OFFSET)
     vo = VisualOdometry(cfg, syn.left_K(W / 640.0), syn.focal_length_px() * (W / 640.0), syn.baseline(),
                         np.ones((H, W), bool), seed=0)
     n_kp = vo.keypoints.shape[0]
+    if args.channels_last:
+        vo.flow_solver.model.to(memory_format=torch.channels_last)
+        vo.disparity_solver.model.to(memory_format=torch.channels_last)
 
     # synthetic chunk: B+1 consecutive stereo frames, different per rank, resident in HBM
     left, right = syn.stereo_sequence(seed=100 + rank, frames=B + 1, h=H, w=W)

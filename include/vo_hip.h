@@ -38,6 +38,17 @@ int vo_version(void);
 const char* vo_last_error(void);
 
 /* ---------------------------------------------------------------------------
+ * Input stage: (frames,H,W) uint8 gray -> (frames,3,H+pt+pb,W+pl+pr) float32, the gray
+ * value replicated into the three channels, borders replicate-padded, and with
+ * normalize != 0 mapped to 2*(x/255)-1.  Stands for _loadImage + InputPadder.pad +
+ * the models' own normalisation: flow/flow_map_RAFT.py:69-72,91-106,
+ * stereo/stereo_disparity_RAFT.py:79-82,97-110.  Padded width must be a multiple of 4.
+ * ------------------------------------------------------------------------- */
+int vo_prepare_images(const uint8_t* gray, float* out, int frames, int H, int W,
+                      int pad_left, int pad_right, int pad_top, int pad_bottom,
+                      int normalize, void* stream);
+
+/* ---------------------------------------------------------------------------
  * All-pairs correlation volume (RAFT CorrBlock / RAFT-Stereo CorrBlock1D "reg").
  * Call sites in the reference: flow/flow_map_RAFT.py:15,42,81 and
  * stereo/stereo_disparity_RAFT.py:15,39,46,91 (the model code itself lives in
@@ -144,6 +155,25 @@ int vo_pair_correspondences(const double* kp, int64_t kp_batch_stride,
 int vo_kabsch_batch(const double* P, const double* Q, const uint8_t* weight,
                     const double* offset_host, double* T_out, int32_t* n_used_out,
                     int batch, int N, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * CameraRansacXform.compute_camera_xform -- camera/camera_svd_xform.py:52-149,
+ * batched: one 256-lane workgroup per pair, one 3-point hypothesis per lane per round.
+ * P, Q: (B,N,3) float64, 3 <= N <= 65535; weight: (B,N) uint8 or NULL.
+ * A hypothesis' inliers are the weighted points with |R p + t - q| < threshold; the
+ * FIRST hypothesis with the strictly largest count wins and the pose is refitted on
+ * its inliers (identity when fewer than 3).  The reference samples from NumPy's
+ * unseeded global generator; here triple h of pair b is a pure function of
+ * (seed, b, h): s = splitmix64(seed ^ (b << 32 | h)); i0 = s % n;
+ * s = splitmix64(s); i1 = s % (n-1), skipping i0; s = splitmix64(s); i2 = s % (n-2),
+ * skipping both (n = number of weighted points, indices into their compacted order).
+ * T_out: (B,4,4) float64; n_inliers_out: (B) int32 inliers of the winner (-1 when a
+ * pair has fewer than 3 weighted points); inlier_mask_out: (B,N) uint8 or NULL.
+ * ------------------------------------------------------------------------- */
+int vo_ransac_kabsch_batch(const double* P, const double* Q, const uint8_t* weight,
+                           double threshold, int iterations, uint64_t seed,
+                           double* T_out, int32_t* n_inliers_out, uint8_t* inlier_mask_out,
+                           int batch, int N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -205,6 +205,42 @@ def ransac_kabsch(P, Q, threshold=0.05, iterations=1000, choice=None):
     return np.eye(3), np.zeros(3)
 
 
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def counter_triples(seed: int, pair: int):
+    """The hypothesis triples of the HIP RANSAC kernel (include/vo_hip.h,
+    vo_ransac_kabsch_batch) as a ``choice`` callable for ``ransac_kabsch``: call h
+    returns triple h of ``pair``, three distinct indices in [0, n)."""
+    state = {"h": 0}
+
+    def choice(n: int):
+        s = _splitmix64((seed & _M64) ^ ((pair << 32) | state["h"]))
+        state["h"] += 1
+        i0 = s % n
+        s = _splitmix64(s)
+        i1 = s % (n - 1)
+        if i1 >= i0:
+            i1 += 1
+        s = _splitmix64(s)
+        i2 = s % (n - 2)
+        lo, hi = min(i0, i1), max(i0, i1)
+        if i2 >= lo:
+            i2 += 1
+        if i2 >= hi:
+            i2 += 1
+        return np.array([i0, i1, i2])
+
+    return choice
+
+
 # --------------------------------------------------------------------------
 # one frame pair of the tracking loop                  test_camera_tracking.py
 # --------------------------------------------------------------------------

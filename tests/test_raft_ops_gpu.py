@@ -262,3 +262,37 @@ def test_plugin_wrappers(vo):
         disp_solver.compute_disparity(left[0], None)
     with pytest.raises(TypeError):
         disp_solver.compute_disparity(left[0], 7)
+
+
+@pytest.mark.parametrize("F,H,W,div", [(3, 480, 640, 8), (2, 100, 130, 8), (2, 100, 130, 32), (1, 720, 1280, 32), (2, 37, 52, 8)])
+def test_prepare_images_matches_host_input_stage(vo, F, H, W, div):
+    """uint8 gray -> 3 channels, replicate pad, 2*(x/255)-1: bit-exact with the
+    wrapper's conversion + InputPadder + the models' entry normalisation."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    g = torch.Generator().manual_seed(F * H + W)
+    gray = torch.randint(0, 256, (F, H, W), generator=g, dtype=torch.uint8)
+    got, pads = ops.prepare_images(gray.to(DEV), div, normalize=True)
+    rgb = gray.float()[:, None].expand(-1, 3, -1, -1).contiguous()
+    ref_img, ref_pads = raft_ref.pad_to_multiple(rgb, div)
+    assert pads == ref_pads and got.shape == ref_img.shape and got.shape[-1] % div == 0 and got.shape[-2] % div == 0
+    assert torch.equal(got.cpu(), 2 * (ref_img / 255.0) - 1.0)
+    raw, _ = ops.prepare_images(gray.to(DEV), div, normalize=False)
+    assert torch.equal(raw.cpu(), ref_img)
+    assert torch.equal(raft_ref.unpad(raw.cpu(), pads), rgb)
+
+
+def test_sequence_entry_points_match_image_entry_points(vo):
+    from visual_odometry_amd import synthetic as syn
+    from visual_odometry_amd.raft.models import RAFTStereoConfig
+    from visual_odometry_amd.raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT, gray_batch_to_rgb
+    left, right = syn.stereo_sequence(4, 3, 100, 130)
+    l, r = torch.from_numpy(left).to(DEV), torch.from_numpy(right).to(DEV)
+    fs = HipOpticalFlowRAFT(None, None, iters=2)
+    a = fs.compute_flow_sequence(l)
+    b = fs.compute_flow_batch(gray_batch_to_rgb(l[:-1]), gray_batch_to_rgb(l[1:]))
+    assert a.shape == (2, 2, 100, 130) and _epe(a, b) < 1e-3
+    ds = HipDisparityRAFT(None, None, iters=2, config=RAFTStereoConfig.realtime())
+    da = ds.compute_disparity_gray_batch(l, r)
+    db = ds.compute_disparity_batch(gray_batch_to_rgb(l), gray_batch_to_rgb(r))
+    assert da.shape == (3, 100, 130) and (da - db).abs().mean().item() < 1e-3

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libvo_hip.so")
@@ -18,6 +18,7 @@ _P, _I, _L, _D, _F = c_void_p, c_int, c_int64, c_double, c_float
 
 # name -> argtypes; every function returns int except the two below.
 SIGNATURES = {
+    "vo_prepare_images": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_corr_volume_2d": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_1d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_corr_pyramid_2d": [_P, _P, _P, _P, _L, _I, _I, _P],
@@ -31,6 +32,7 @@ SIGNATURES = {
     "vo_keypoints_flow_3d": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vo_pair_correspondences": [_P, _L, _P, _P, _P, _P, _D, _D, _D, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vo_kabsch_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vo_ransac_kabsch_batch": [_P, _P, _P, _D, _I, c_uint64, _P, _P, _P, _I, _I, _P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["vo_version", "vo_last_error"])
 

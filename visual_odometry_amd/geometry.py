@@ -9,6 +9,7 @@ that take and return GPU tensors so a whole chunk of frame pairs stays in HBM.
   HipKeypoints3DXform   keypoints/keypoints_3d.py:5-70
   HipKeypoints3DFlow    keypoints/keypoints_3d_flow.py:8-88
   HipCameraSvdXform     camera/camera_svd_xform.py:4-48
+  HipCameraRansacXform  camera/camera_svd_xform.py:52-149
 """
 from __future__ import annotations
 
@@ -193,3 +194,28 @@ class HipCameraSvdXform(CameraXformInterface):
         """(B,N,3) float64 GPU point sets (+ optional (B,N) uint8 weights) ->
         T (B,4,4) float64, n_used (B) int32."""
         return ops.kabsch_batch(P, Q, weight, self.offset)
+
+
+class HipCameraRansacXform(CameraXformInterface):
+    """3-point RANSAC + inlier refit.  ``seed`` fixes the hypothesis triples (the
+    reference's own sampling is unseeded and therefore not reproducible)."""
+
+    def __init__(self, threshold: float = 0.05, iterations: int = 1000, seed: int = 0):
+        self.threshold = threshold
+        self.iterations = iterations
+        self.seed = seed
+
+    def compute_camera_xform(self, P: np.ndarray, Q: np.ndarray):
+        P, Q = np.asarray(P), np.asarray(Q)
+        if P.ndim != 2 or Q.ndim != 2 or P.shape[0] != Q.shape[0] or P.shape[1] != 3 or Q.shape[1] != 3:
+            raise ValueError("Input arrays must be of shape (N, 3)")
+        if P.shape[0] < 3:
+            raise ValueError("At least 3 points are required for RANSAC.")
+        T, _ = self.compute_camera_xform_batch(_to_gpu(P[None], np.float64), _to_gpu(Q[None], np.float64))
+        T = T[0].cpu().numpy()
+        return T[:3, :3].copy(), T[:3, 3].copy()
+
+    def compute_camera_xform_batch(self, P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None):
+        """(B,N,3) float64 GPU point sets (+ optional (B,N) uint8 weights) ->
+        T (B,4,4) float64, n_inliers (B) int32 (-1: fewer than 3 weighted points)."""
+        return ops.ransac_kabsch_batch(P, Q, weight, self.threshold, self.iterations, self.seed)

@@ -72,6 +72,27 @@ def _host9(Kinv) -> "ctypes.Array":
 
 # ------------------------------------------------------------------ RAFT ops
 
+def pad_amounts(ht: int, wd: int, divis_by: int):
+    """[left, right, top, bottom] replicate padding up to a multiple of ``divis_by``,
+    split evenly with the odd pixel at the far side."""
+    ph = (((ht // divis_by) + 1) * divis_by - ht) % divis_by
+    pw = (((wd // divis_by) + 1) * divis_by - wd) % divis_by
+    return [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
+
+
+def prepare_images(gray: torch.Tensor, divis_by: int = 8, normalize: bool = True):
+    """(F,H,W) uint8 GPU frames -> ((F,3,Hp,Wp) float32, pads): three equal channels,
+    replicate padding to a multiple of ``divis_by``, optional 2*(x/255)-1."""
+    if gray.dim() != 3:
+        raise ValueError("gray frames must be (F,H,W)")
+    F_, H, W = gray.shape
+    pads = pad_amounts(H, W, divis_by)
+    out = torch.empty((F_, 3, H + pads[2] + pads[3], W + pads[0] + pads[1]), device=gray.device, dtype=torch.float32)
+    _call("vo_prepare_images", _dev(gray, "gray", torch.uint8), out.data_ptr(), F_, H, W, *pads,
+          int(bool(normalize)), _stream())
+    return out, pads
+
+
 def pyramid_shapes_2d(h2: int, w2: int, levels: int = MAX_LEVELS):
     out = [(h2, w2)]
     for _ in range(levels - 1):
@@ -293,3 +314,22 @@ def kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None =
     _call("vo_kabsch_batch", _dev(P, "P", torch.float64), _dev(Q, "Q", torch.float64),
               _opt(weight, "weight", torch.uint8), off, T.data_ptr(), n_used.data_ptr(), B, N, _stream())
     return T, n_used
+
+
+def ransac_kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None,
+                        threshold: float = 0.05, iterations: int = 1000, seed: int = 0, want_mask: bool = False):
+    """(B,N,3) float64 point sets -> T (B,4,4) f64, n_inliers (B) int32 [, inlier mask (B,N) bool]."""
+    if P.dim() != 3 or P.shape[2] != 3 or Q.shape != P.shape:
+        raise ValueError("Input arrays must be of shape (N, 3)")
+    B, N, _ = P.shape
+    if N < 3:
+        raise ValueError("At least 3 points are required for RANSAC.")
+    if weight is not None and tuple(weight.shape) != (B, N):
+        raise ValueError("weight must be (B,N)")
+    T = torch.empty((B, 4, 4), device=P.device, dtype=torch.float64)
+    n_inl = torch.empty((B,), device=P.device, dtype=torch.int32)
+    mask = torch.empty((B, N), device=P.device, dtype=torch.uint8) if want_mask else None
+    _call("vo_ransac_kabsch_batch", _dev(P, "P", torch.float64), _dev(Q, "Q", torch.float64),
+          _opt(weight, "weight", torch.uint8), float(threshold), int(iterations), int(seed) & (2 ** 64 - 1),
+          T.data_ptr(), n_inl.data_ptr(), 0 if mask is None else mask.data_ptr(), B, N, _stream())
+    return (T, n_inl, mask.bool()) if want_mask else (T, n_inl)

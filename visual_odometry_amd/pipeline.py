@@ -26,9 +26,10 @@ import numpy as np
 import torch
 
 from . import ops
-from .geometry import HipCameraSvdXform, HipKeypoints3DFlow, HipKeypoints3DXform, HipStereoDepth, UniformKeyPoints
-from .raft.models import RAFTStereoConfig, normalize_image
-from .raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT, gray_batch_to_rgb
+from .geometry import (HipCameraRansacXform, HipCameraSvdXform, HipKeypoints3DFlow, HipKeypoints3DXform,
+                       HipStereoDepth, UniformKeyPoints)
+from .raft.models import RAFTStereoConfig
+from .raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT
 
 
 @dataclass
@@ -41,6 +42,10 @@ class VOConfig:
     max_dz: float = 1.0                   # :198
     min_points: int = 4                   # :188
     camera_offset: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    pose: str = "svd"                     # "svd": CameraSvdXform; "ransac": CameraRansacXform (:82)
+    ransac_threshold: float = 0.05        # camera_svd_xform.py:58
+    ransac_iterations: int = 1000
+    ransac_seed: int = 0
 
 
 class _Rig:
@@ -65,23 +70,23 @@ class VisualOdometry:
         self.pts_src = UniformKeyPoints(mask)
         self.pts_xform = HipKeypoints3DXform(cam)
         self.pts_flow = HipKeypoints3DFlow(cam, self.pts_xform, mask)
-        self.cam_estimator = HipCameraSvdXform(np.array(cfg.camera_offset))
+        if cfg.pose == "ransac":
+            self.cam_estimator = HipCameraRansacXform(cfg.ransac_threshold, cfg.ransac_iterations, cfg.ransac_seed)
+        elif cfg.pose == "svd":
+            self.cam_estimator = HipCameraSvdXform(np.array(cfg.camera_offset))
+        else:
+            raise ValueError("VOConfig.pose must be 'svd' or 'ransac'")
         self.keypoints = self.pts_src.get_keypoints_device(cfg.max_keypoints)
 
     # -- stages ------------------------------------------------------------
     def depth_maps(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
         """(F,H,W) gray GPU frames -> (F,H,W) float32 depth."""
-        disp = self.disparity_solver.compute_disparity_batch(gray_batch_to_rgb(left), gray_batch_to_rgb(right))
+        disp = self.disparity_solver.compute_disparity_gray_batch(left, right)
         return ops.disparity_to_depth(disp, float(self._fxB), self._f64)
 
     def flows(self, left: torch.Tensor) -> torch.Tensor:
         """(F,H,W) gray GPU frames -> (F-1,2,H,W) flow between consecutive frames."""
-        rgb = gray_batch_to_rgb(left)
-        h, w = rgb.shape[-2:]
-        if h % 8 == 0 and w % 8 == 0:      # no padding: share one encoder pass per frame
-            fm = self.flow_solver.model.features(normalize_image(rgb))
-            return self.flow_solver.compute_flow_batch(rgb[:-1], rgb[1:], fmap1=fm[:-1], fmap2=fm[1:])
-        return self.flow_solver.compute_flow_batch(rgb[:-1].contiguous(), rgb[1:].contiguous())
+        return self.flow_solver.compute_flow_sequence(left)
 
     def poses(self, depth: torch.Tensor, flow: torch.Tensor):
         """(F,H,W) depth + (F-1,2,H,W) flow -> T_rel (F-1,4,4) f64, skipped (F-1) bool."""
@@ -90,8 +95,9 @@ class VisualOdometry:
             self.keypoints, depth[:-1], depth[1:], flow, c.min_depth, c.max_depth, c.max_dz)
         T, n_used = self.cam_estimator.compute_camera_xform_batch(P1, P2, wgt)
         # the reference skips a pair when fewer than 4 points survive the range filter;
-        # a pair whose final selection is empty has no pose at all (NaN) and is skipped too
-        skipped = (n_in < c.min_points) | (n_used < 1)
+        # a pair whose final selection is empty has no pose at all (NaN from Kabsch, an
+        # exception from RANSAC, flagged -1 here) and is skipped too
+        skipped = (n_in < c.min_points) | (n_used < (0 if c.pose == "ransac" else 1))
         return T, skipped
 
     # -- chunk / sequence --------------------------------------------------

@@ -78,14 +78,18 @@ class RAFTFlow(nn.Module):
         return pixel_major(self.fnet(images))
 
     @torch.no_grad()
-    def forward(self, image1, image2, iters: int = 12, flow_init=None, fmap1=None, fmap2=None):
-        """image1/2: (B,3,H,W) float 0..255, H and W multiples of 8.  Precomputed
-        pixel-major feature maps may be passed so that consecutive pairs of a
-        sequence share the encoder pass of their common frame."""
+    def forward(self, image1, image2, iters: int = 12, flow_init=None, fmap1=None, fmap2=None,
+                normalized: bool = False):
+        """image1/2: (B,3,H,W) float 0..255 (or already in [-1,1] with
+        ``normalized=True``), H and W multiples of 8.  Precomputed pixel-major
+        feature maps may be passed so that consecutive pairs of a sequence share
+        the encoder pass of their common frame."""
         c = self.cfg
-        image1 = normalize_image(image1)
+        if not normalized:
+            image1 = normalize_image(image1)
         if fmap1 is None or fmap2 is None:
-            image2 = normalize_image(image2)
+            if not normalized:
+                image2 = normalize_image(image2)
             both = self.features(torch.cat([image1, image2], dim=0))
             fmap1, fmap2 = both[: image1.shape[0]], both[image1.shape[0]:]
         B, H8, W8, _ = fmap1.shape
@@ -145,13 +149,15 @@ class RAFTStereo(nn.Module):
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=c.n_downsample)
 
     @torch.no_grad()
-    def forward(self, image1, image2, iters: int = 12, flow_init=None):
-        """image1/2: (B,3,H,W) float 0..255, H and W multiples of 32.  Returns
-        (low-res x-flow field (B,2,h,w), upsampled disparity (B,1,H,W), negative
-        for a rectified left/right pair)."""
+    def forward(self, image1, image2, iters: int = 12, flow_init=None, normalized: bool = False):
+        """image1/2: (B,3,H,W) float 0..255 (or already in [-1,1] with
+        ``normalized=True``), H and W multiples of 32.  Returns (low-res x-flow field
+        (B,2,h,w), upsampled disparity (B,1,H,W), negative for a rectified
+        left/right pair)."""
         c = self.cfg
-        image1 = normalize_image(image1)
-        image2 = normalize_image(image2)
+        if not normalized:
+            image1 = normalize_image(image1)
+            image2 = normalize_image(image2)
         B = image1.shape[0]
 
         cnet_list = self.cnet(image1, num_layers=c.n_gru_layers)

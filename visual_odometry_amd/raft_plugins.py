@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .interfaces import OpticalFlowInterface, StereoDisparityInterface
 from .raft.models import RAFTFlow, RAFTFlowConfig, RAFTStereo, RAFTStereoConfig, load_checkpoint
 
@@ -108,6 +109,16 @@ class HipOpticalFlowRAFT(OpticalFlowInterface):
         return _unpad(flow_up, pads).contiguous() if any(pads) else flow_up
 
 
+    def compute_flow_sequence(self, gray: torch.Tensor) -> torch.Tensor:
+        """(F,H,W) uint8 GPU frames -> (F-1,2,H,W) flow between consecutive frames.
+        The input stage (3-channel replication, padding, normalisation) is one HIP
+        kernel and the feature encoder runs once per frame, not twice per pair."""
+        imgs, pads = ops.prepare_images(gray, 8, normalize=True)
+        fm = self.model.features(imgs)
+        _, flow_up = self.model(imgs[:-1], imgs[1:], iters=self.iters, fmap1=fm[:-1], fmap2=fm[1:], normalized=True)
+        return _unpad(flow_up, pads).contiguous() if any(pads) else flow_up
+
+
 class HipDisparityRAFT(StereoDisparityInterface):
     def __init__(self, checkpoint: Optional[str] = None, rectification=None, iters: int = 32,
                  config: Optional[RAFTStereoConfig] = None, seed: int = 1):
@@ -145,5 +156,13 @@ class HipDisparityRAFT(StereoDisparityInterface):
             image1 = F.pad(image1, pads, mode="replicate")
             image2 = F.pad(image2, pads, mode="replicate")
         _, disp = self.model(image1, image2, iters=self.iters)
+        disp = _unpad(disp, pads) if any(pads) else disp
+        return disp[:, 0].contiguous()
+
+    def compute_disparity_gray_batch(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
+        """(F,H,W) uint8 GPU frames -> disparity (F,H,W) float32; input stage on the GPU."""
+        image1, pads = ops.prepare_images(left, 32, normalize=True)
+        image2, _ = ops.prepare_images(right, 32, normalize=True)
+        _, disp = self.model(image1, image2, iters=self.iters, normalized=True)
         disp = _unpad(disp, pads) if any(pads) else disp
         return disp[:, 0].contiguous()
