@@ -117,3 +117,31 @@ def trace_case(seed=21, pairs=8, h=480, w=640, noise_px=0.1):
     """Eight planar-scene frame pairs for the end-to-end geometry trace."""
     rng = np.random.default_rng(seed)
     return [syn.plane_pair(rng, h, w, K_for(w), noise_px=noise_px) for _ in range(pairs)]
+
+
+def trajectory_files(directory, seed=77, n_images=12, n_gt=400):
+    """Write a synthetic ``left_images.txt`` and ``groundtruth.txt`` (the UZH-FPV
+    text layouts: ``id timestamp image_name`` and ``timestamp tx ty tz qx qy qz qw``,
+    '#' comment header, ground-truth rows deliberately not in time order) and return
+    (image_list_path, gt_path, computed_positions)."""
+    import os
+    rng = np.random.default_rng(seed)
+    t0 = 1540821844.0
+    gt_t = t0 + np.sort(rng.uniform(0, 2.0, n_gt))
+    gt = np.column_stack([gt_t, rng.uniform(-5, 5, (n_gt, 3)), rng.normal(0, 1, (n_gt, 4))])
+    order = rng.permutation(n_gt)
+    img_t = t0 + np.linspace(0.1, 2.6, n_images)        # the last few fall outside the GT span
+    img_t[3] = gt_t[50]                                  # exact hit
+    img_t[4] = gt_t[60] + 0.05 * 0.999                   # just inside the tolerance of a sparse spot
+    gtp = os.path.join(directory, "groundtruth.txt")
+    imp = os.path.join(directory, "left_images.txt")
+    with open(gtp, "w") as f:
+        f.write("# timestamp tx ty tz qx qy qz qw\n")
+        for r in gt[order]:
+            f.write(" ".join(repr(float(v)) for v in r) + "\n")
+    with open(imp, "w") as f:
+        f.write("# id timestamp image_name\n")
+        for i, t in enumerate(img_t):
+            f.write(f"{i} {float(t)!r} img/image_0_{i}.png\n")
+    computed = rng.uniform(-1, 1, (n_images + 2, 3))     # two more poses than images
+    return imp, gtp, computed

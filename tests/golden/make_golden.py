@@ -133,6 +133,18 @@ def main():
          T_global=np.array(T_glob),
          in_sum=cases.checksum(*[p[k] for p in cases.trace_case() for k in ("depth1", "depth2", "flow")]))
 
+    # G8 trajectory evaluation helpers (utilities/data_utils.py) ------------------
+    import tempfile
+    from utilities import data_utils
+    with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(io.StringIO()):
+        imp, gtp, computed = cases.trajectory_files(d)
+        matched = data_utils.match_ground_truth_positions(computed, imp, gtp)
+        pos = data_utils.read_ground_truth_positions(gtp, skip=7)
+        xf = data_utils.read_ground_truth_transforms(gtp, skip=20)
+    save("g8_trajectory", matched_gt=np.array([m[1] for m in matched], dtype=np.float64),
+         matched_est=np.array([m[0] for m in matched]), positions_skip7=pos, transforms_skip20=np.array(xf),
+         quat_R=data_utils.quaternion_to_rotation_matrix(0.3, -0.2, 0.9, -0.4), in_sum=cases.checksum(computed))
+
 
 if __name__ == "__main__":
     main()
