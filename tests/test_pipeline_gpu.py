@@ -72,3 +72,41 @@ def test_short_chunk_is_rejected(vo):
     z = torch.zeros((1, 64, 96), dtype=torch.uint8, device="cuda")
     with pytest.raises(ValueError):
         pipe.process_chunk(z, z)
+
+
+def test_high_resolution_dense_grid(vo):
+    """1280x720 with the dense ~20k-point grid: stereo pads 720 -> 736 rows, the flow
+    volume is 14400^2 per pair, Kabsch reduces 19928 weighted points per pair."""
+    from oracle import raft_ref
+    from visual_odometry_amd.raft_plugins import gray_batch_to_rgb
+    H, W, F = 720, 1280, 2
+    pipe = _vo(H, W, iters=2, n_kp=20000)
+    assert pipe.keypoints.shape == (19928, 2)
+    left, right = syn.stereo_sequence(13, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    depth = pipe.depth_maps(l, r)
+    flow = pipe.flows(l)
+    assert depth.shape == (F, H, W) and flow.shape == (F - 1, 2, H, W)
+    # networks against the stock-op restatement at this size
+    rgb_l, rgb_r = gray_batch_to_rgb(l), gray_batch_to_rgb(r)
+    _, flow_ref = raft_ref.raft_flow_forward(pipe.flow_solver.model, rgb_l[:1], rgb_l[1:], 2)
+    assert (flow - flow_ref).pow(2).sum(1).sqrt().mean().item() < 0.05
+    pad_l, pads = raft_ref.pad_to_multiple(rgb_l, 32)
+    pad_r, _ = raft_ref.pad_to_multiple(rgb_r, 32)
+    assert pad_l.shape[-2:] == (736, 1280)
+    _, disp_ref = raft_ref.raft_stereo_forward(pipe.disparity_solver.model, pad_l, pad_r, 2)
+    disp_ref = raft_ref.unpad(disp_ref, pads)[:, 0]
+    disp = pipe.disparity_solver.compute_disparity_gray_batch(l, r)
+    assert (disp - disp_ref).abs().mean().item() < 0.05
+    # geometry half on the dense grid against the NumPy oracle (bit-exact selection)
+    T, skipped = pipe.poses(depth, flow)
+    kp = pipe.pts_src.get_keypoints(None, 20000)
+    P1, P2, wgt, n_in = ref.pair_correspondences(kp, depth[0].cpu().numpy(), depth[1].cpu().numpy(),
+                                                 flow[0].cpu().numpy(), pipe.pts_xform.K_inv)
+    from visual_odometry_amd import ops
+    _, _, wd, nd = ops.pair_correspondences(pipe.keypoints, depth[:-1], depth[1:], flow, pipe.pts_xform.K_inv)
+    assert np.array_equal(wd[0].cpu().numpy().astype(bool), wgt) and int(nd[0]) == n_in
+    if wgt.sum() >= 3:
+        R, t = ref.kabsch(P1[wgt], P2[wgt], np.array(syn.CAMERA_OFFSET))
+        np.testing.assert_allclose(T[0, :3, :3].cpu().numpy(), R, atol=1e-8)
+        np.testing.assert_allclose(T[0, :3, 3].cpu().numpy(), t, atol=1e-8)
