@@ -197,8 +197,11 @@ def main():
     work = algorithmic_work(B, H, W, args.iters, n_kp)
     kernels = {}
     for name, evs in rec.items():
-        ms = [s.elapsed_time(e) for (s, e) in evs]
-        w = work.get(name, {})
+        ms = [ev[0].elapsed_time(ev[1]) for ev in evs]
+        w = dict(work.get(name, {}))
+        recorded = sum(ev[2] for ev in evs)
+        if recorded and "bytes" not in w:          # kernels whose work depends on the tensor they are handed
+            w = {"launches": len(evs) // args.steps, "bytes": recorded / args.steps}
         per_step_ms = sum(ms) / args.steps
         entry = {"launches_per_step": len(ms) // args.steps, "avg_us": 1e3 * sum(ms) / len(ms),
                  "ms_per_step": per_step_ms}
@@ -208,6 +211,9 @@ def main():
         if "flops" in w:
             entry["TFLOPs"] = w["flops"] / (per_step_ms * 1e-3) / 1e12
         kernels[name] = entry
+    work = {k: (work[k] if k in work else {"launches": v["launches_per_step"],
+                                            "bytes": v.get("alg_GB_per_launch", 0) * 1e9 * v["launches_per_step"]})
+            for k, v in kernels.items()}
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     d = kernels[dom]
     if "TFLOPs" in d:

@@ -296,3 +296,66 @@ def test_sequence_entry_points_match_image_entry_points(vo):
     da = ds.compute_disparity_gray_batch(l, r)
     db = ds.compute_disparity_batch(gray_batch_to_rgb(l), gray_batch_to_rgb(r))
     assert da.shape == (3, 100, 130) and (da - db).abs().mean().item() < 1e-3
+
+
+def test_fused_encoder_passes_match_stock_operators(vo):
+    """instance-norm+ReLU, folded batch-norm+ReLU and add+ReLU against torch."""
+    import torch.nn as nn
+    from visual_odometry_amd import ops
+    from visual_odometry_amd.raft.layers import BasicEncoder, fused_passes
+    for shape in [(2, 5, 37, 41), (1, 64, 60, 80), (3, 8, 16, 16), (1, 3, 1, 7)]:
+        x = _rand(*shape, seed=21, scale=2.0).to(DEV) + 0.5
+        for relu in (True, False):
+            want = nn.functional.instance_norm(x, eps=1e-5)
+            want = torch.relu(want) if relu else want
+            got = ops.instance_norm_relu_(x.clone(), 1e-5, relu)
+            assert (got - want).abs().max().item() < 2e-5
+        bn = nn.BatchNorm2d(shape[1]).to(DEV).eval()
+        with torch.no_grad():
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(); bn.bias.normal_()
+            want = torch.relu(bn(x))
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            got = ops.channel_affine_relu_(x.clone(), scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous(), True)
+        assert (got - want).abs().max().item() < 2e-5
+        y = _rand(*shape, seed=22).to(DEV)
+        assert torch.equal(ops.add_relu_(x.clone(), y), torch.relu(x + y))
+    # a whole encoder, fused against stock, both norm kinds
+    for kind in ("instance", "batch"):
+        torch.manual_seed(3)
+        enc = BasicEncoder(64, kind, downsample=2).to(DEV).eval()
+        img = _rand(2, 3, 64, 96, seed=23).to(DEV)
+        with torch.no_grad():
+            a = enc(img)
+            with fused_passes():
+                b = enc(img)
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
+
+
+def test_fused_gru_steps_match_stock_operators(vo):
+    from visual_odometry_amd.raft.layers import fused_passes
+    from visual_odometry_amd.raft.update import BasicMultiUpdateBlock, BasicUpdateBlock
+    torch.manual_seed(5)
+    B, H, W = 2, 12, 20
+    blk = BasicUpdateBlock().to(DEV).eval()
+    net, inp = torch.tanh(_rand(B, 128, H, W, seed=30)).to(DEV), torch.relu(_rand(B, 128, H, W, seed=31)).to(DEV)
+    corr, flow = _rand(B, 324, H, W, seed=32).to(DEV), _rand(B, 2, H, W, seed=33).to(DEV)
+    with torch.no_grad():
+        a = blk(net, inp, corr, flow, want_mask=True)
+        with fused_passes():
+            b = blk(net, inp, corr, flow, want_mask=True)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() < 1e-4 * max(1.0, x.abs().max().item())
+    for layers, dims in ((2, [64, 64, 64]), (3, [128, 128, 128])):
+        mb = BasicMultiUpdateBlock(dims, layers, 2).to(DEV).eval()
+        nets = [torch.tanh(_rand(B, dims[2 - i], H >> i, W >> i, seed=40 + i)).to(DEV) for i in range(layers)]
+        inps = [[_rand(B, dims[2 - i], H >> i, W >> i, seed=50 + 3 * i + k).to(DEV) for k in range(3)] for i in range(layers)]
+        # context terms as channel slices of one tensor, as the model produces them
+        inps = [list(torch.cat(t, dim=1).split(t[0].shape[1], dim=1)) for t in inps]
+        corr1, flow1 = _rand(B, 36, H, W, seed=60).to(DEV), _rand(B, 2, H, W, seed=61).to(DEV)
+        with torch.no_grad():
+            a = mb([n.clone() for n in nets], inps, corr1, flow1, iter32=layers == 3, iter16=layers >= 2)
+            with fused_passes():
+                b = mb([n.clone() for n in nets], inps, corr1, flow1, iter32=layers == 3, iter16=layers >= 2)
+        for x, y in zip(a[0], b[0]):
+            assert (x - y).abs().max().item() < 1e-4
+        assert (a[1] - b[1]).abs().max().item() < 1e-3 and (a[2] - b[2]).abs().max().item() < 1e-4

@@ -1,0 +1,129 @@
+// Fused normalisation / activation passes for the conv encoders (inference only).
+//
+// The encoders of both networks run norm -> ReLU after every convolution and
+// ReLU(x + y) after every residual block, on tensors of up to 1.3 GB (RAFT-Stereo's
+// stem works at full resolution).  As separate framework kernels that is 5-7 HBM
+// passes per convolution output (statistics, transform, clamp, add, clamp); fused
+// here it is 3 for instance norm (one read for the statistics, one read+write to
+// apply) and 2 for everything else.  All kernels work IN PLACE on the convolution
+// output, planes are (n, c) slices of an NCHW tensor, 16 bytes per lane.
+#include "vo_common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, VO_WAVE);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += scratch[w];
+    return t;
+}
+
+// InstanceNorm2d (no affine, biased variance) + optional ReLU; one workgroup per plane.
+__global__ __launch_bounds__(256) void instnorm_kernel(float* __restrict__ x, int64_t hw, float eps, int relu) {
+    __shared__ double scratch[4];
+    float* p = x + (int64_t)blockIdx.x * hw;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (hw >> 2) : 0;
+    float s = 0.0f, ss = 0.0f;
+    double ds = 0.0, dss = 0.0;
+    int since = 0;
+    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        if (++since == 64) { ds += s; dss += ss; s = 0.0f; ss = 0.0f; since = 0; }   // bound the float32 run length
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < hw; i += blockDim.x) { const float v = p[i]; s += v; ss += v * v; }
+    ds += s; dss += ss;
+    const double tot = block_sum(ds, scratch);
+    const double tot2 = block_sum(dss, scratch);
+    const double mean = tot / (double)hw;
+    double var = tot2 / (double)hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        float4 v = reinterpret_cast<float4*>(p)[i];
+        v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        reinterpret_cast<float4*>(p)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < hw; i += blockDim.x) {
+        float v = (p[i] - m) * r;
+        p[i] = relu ? fmaxf(v, 0.0f) : v;
+    }
+}
+
+// y = x * scale[c] + shift[c] (+ ReLU): BatchNorm2d in inference with the running
+// statistics folded into scale / shift.  grid.y = plane, grid.x strides the plane.
+__global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int C, int64_t hw, int relu) {
+    const int64_t plane = blockIdx.y;
+    const float a = scale[plane % C], b = shift[plane % C];
+    float* p = x + plane * hw;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (hw >> 2) : 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t; i < n4; i += stride) {
+        float4 v = reinterpret_cast<float4*>(p)[i];
+        v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        reinterpret_cast<float4*>(p)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + t; i < hw; i += stride) {
+        const float v = p[i] * a + b;
+        p[i] = relu ? fmaxf(v, 0.0f) : v;
+    }
+}
+
+// a = relu(a + b)
+__global__ __launch_bounds__(256) void add_relu_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    const int64_t n4 = al ? (n >> 2) : 0;
+    for (int64_t i = t; i < n4; i += stride) {
+        float4 u = reinterpret_cast<float4*>(a)[i];
+        const float4 v = reinterpret_cast<const float4*>(b)[i];
+        u.x = fmaxf(u.x + v.x, 0.0f); u.y = fmaxf(u.y + v.y, 0.0f); u.z = fmaxf(u.z + v.z, 0.0f); u.w = fmaxf(u.w + v.w, 0.0f);
+        reinterpret_cast<float4*>(a)[i] = u;
+    }
+    for (int64_t i = (n4 << 2) + t; i < n; i += stride) a[i] = fmaxf(a[i] + b[i], 0.0f);
+}
+
+}  // namespace
+
+extern "C" int vo_instance_norm_relu(float* x, int64_t planes, int64_t hw, float eps, int relu, void* stream) {
+    VO_REQUIRE(x, "vo_instance_norm_relu: null pointer");
+    VO_REQUIRE(planes > 0 && hw > 0, "vo_instance_norm_relu: bad sizes planes=%lld hw=%lld", (long long)planes, (long long)hw);
+    if (planes > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_instance_norm_relu: too many planes");
+    instnorm_kernel<<<dim3((unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, hw, eps, relu);
+    VO_CHECK_LAUNCH("vo_instance_norm_relu");
+    return VO_OK;
+}
+
+extern "C" int vo_channel_affine_relu(float* x, const float* scale, const float* shift, int64_t batch, int C,
+                                      int64_t hw, int relu, void* stream) {
+    VO_REQUIRE(x && scale && shift, "vo_channel_affine_relu: null pointer");
+    VO_REQUIRE(batch > 0 && C > 0 && hw > 0, "vo_channel_affine_relu: bad sizes");
+    const int64_t planes = batch * C;
+    if (planes > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_channel_affine_relu: batch*C=%lld exceeds 65535", (long long)planes);
+    int64_t bx = vo_ceil_div(vo_ceil_div(hw, 4), 256);
+    if (bx > 64) bx = 64;
+    affine_kernel<<<dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, scale, shift, C, hw, relu);
+    VO_CHECK_LAUNCH("vo_channel_affine_relu");
+    return VO_OK;
+}
+
+extern "C" int vo_add_relu(float* a, const float* b, int64_t n, void* stream) {
+    VO_REQUIRE(a && b, "vo_add_relu: null pointer");
+    VO_REQUIRE(n > 0, "vo_add_relu: n=%lld", (long long)n);
+    int64_t blocks = vo_ceil_div(vo_ceil_div(n, 4), 256);
+    if (blocks > 4096) blocks = 4096;
+    add_relu_kernel<<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(a, b, n);
+    VO_CHECK_LAUNCH("vo_add_relu");
+    return VO_OK;
+}

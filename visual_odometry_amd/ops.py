@@ -37,7 +37,8 @@ def set_recorder(rec):
     return old
 
 
-def _call(name: str, *args) -> None:
+def _call(name: str, *args, nbytes: int = 0) -> None:
+    """``nbytes`` = algorithmic bytes of this launch (recorded for roofline reports)."""
     if _recorder is None:
         _lib.call(name, *args)
         return
@@ -46,7 +47,7 @@ def _call(name: str, *args) -> None:
     start.record()
     _lib.call(name, *args)
     end.record()
-    _recorder.setdefault(name, []).append((start, end))
+    _recorder.setdefault(name, []).append((start, end, nbytes))
 
 
 def _dev(t: torch.Tensor, name: str, dtype: torch.dtype) -> int:
@@ -70,6 +71,76 @@ def _host9(Kinv) -> "ctypes.Array":
     return (ctypes.c_double * 9)(*a.tolist())
 
 
+# ------------------------------------------------------- fused encoder passes
+
+def instance_norm_relu_(x: torch.Tensor, eps: float = 1e-5, relu: bool = True) -> torch.Tensor:
+    """In-place InstanceNorm2d (no affine) [+ ReLU] on an NCHW float32 tensor."""
+    N, C, H, W = x.shape
+    _call("vo_instance_norm_relu", _dev(x, "x", torch.float32), N * C, H * W, float(eps), int(relu), _stream(),
+          nbytes=3 * 4 * x.numel())              # statistics read + apply read/write
+    return x
+
+
+def channel_affine_relu_(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """In-place x*scale[c] + shift[c] [+ ReLU] on an NCHW float32 tensor."""
+    N, C, H, W = x.shape
+    if scale.numel() != C or shift.numel() != C:
+        raise ValueError("scale/shift must have one entry per channel")
+    _call("vo_channel_affine_relu", _dev(x, "x", torch.float32), _dev(scale, "scale", torch.float32),
+          _dev(shift, "shift", torch.float32), N, C, H * W, int(relu), _stream(), nbytes=2 * 4 * x.numel())
+    return x
+
+
+def add_relu_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """In-place a = relu(a + b)."""
+    if a.shape != b.shape:
+        raise ValueError("add_relu_: shapes differ")
+    _call("vo_add_relu", _dev(a, "a", torch.float32), _dev(b, "b", torch.float32), a.numel(), _stream(),
+          nbytes=3 * 4 * a.numel())
+    return a
+
+
+def _slice(t, name: str):
+    """A (B,C,H,W) float32 GPU tensor whose (C,H,W) block is dense but whose batch items
+    may be further apart (a channel slice of a bigger NCHW tensor) -> (ptr, batch stride)."""
+    if t is None:
+        return 0, 0
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        raise ValueError(f"{name}: expected a 4-D float32 GPU tensor")
+    B, C, H, W = t.shape
+    st = t.stride()
+    if not (st[3] == 1 and st[2] == W and st[1] == H * W):
+        raise ValueError(f"{name}: channel planes must be dense (got strides {st})")
+    return t.data_ptr(), (st[0] if B > 1 else C * H * W)
+
+
+def gru_gates(zr: torch.Tensor, bias_z, bias_r, cz, cr, h: torch.Tensor, rh_out: torch.Tensor) -> torch.Tensor:
+    """z = sigmoid(zr[:, :C] + bias_z + cz) (returned), rh_out <- sigmoid(zr[:, C:] + bias_r + cr) * h."""
+    B, C2, H, W = zr.shape
+    C = C2 // 2
+    if tuple(h.shape) != (B, C, H, W) or tuple(rh_out.shape) != (B, C, H, W):
+        raise ValueError("gru_gates: h / rh_out must be (B,C,H,W) with zr (B,2C,H,W)")
+    z = torch.empty((B, C, H, W), device=zr.device, dtype=torch.float32)
+    pcz, scz = _slice(cz, "cz"); pcr, scr = _slice(cr, "cr"); ph, sh = _slice(h, "h"); prh, srh = _slice(rh_out, "rh_out")
+    _call("vo_gru_gates", _dev(zr, "zr", torch.float32), _opt(bias_z, "bias_z", torch.float32),
+          _opt(bias_r, "bias_r", torch.float32), pcz, scz, pcr, scr, ph, sh, z.data_ptr(), prh, srh, B, C, H * W,
+          _stream(), nbytes=4 * z.numel() * (5 + (cz is not None) + (cr is not None)))
+    return z
+
+
+def gru_update(q: torch.Tensor, bias_q, cq, z: torch.Tensor, h: torch.Tensor, h_out: torch.Tensor, h_copy=None):
+    """h_out <- (1-z)*h + z*tanh(q + bias_q + cq); h_copy (optional slice) gets the same values."""
+    B, C, H, W = q.shape
+    for t, n in ((z, "z"), (h, "h"), (h_out, "h_out")):
+        if tuple(t.shape) != (B, C, H, W):
+            raise ValueError(f"gru_update: {n} must be (B,C,H,W)")
+    pcq, scq = _slice(cq, "cq"); ph, sh = _slice(h, "h"); po, so = _slice(h_out, "h_out"); pc, sc = _slice(h_copy, "h_copy")
+    _call("vo_gru_update", _dev(q, "q", torch.float32), _opt(bias_q, "bias_q", torch.float32), pcq, scq,
+          _dev(z, "z", torch.float32), ph, sh, po, so, pc, sc, B, C, H * W, _stream(),
+          nbytes=4 * q.numel() * (4 + (cq is not None) + (h_copy is not None)))
+    return h_out
+
+
 # ------------------------------------------------------------------ RAFT ops
 
 def pad_amounts(ht: int, wd: int, divis_by: int):
@@ -89,7 +160,7 @@ def prepare_images(gray: torch.Tensor, divis_by: int = 8, normalize: bool = True
     pads = pad_amounts(H, W, divis_by)
     out = torch.empty((F_, 3, H + pads[2] + pads[3], W + pads[0] + pads[1]), device=gray.device, dtype=torch.float32)
     _call("vo_prepare_images", _dev(gray, "gray", torch.uint8), out.data_ptr(), F_, H, W, *pads,
-          int(bool(normalize)), _stream())
+          int(bool(normalize)), _stream(), nbytes=gray.numel() + 4 * out.numel())
     return out, pads
 
 

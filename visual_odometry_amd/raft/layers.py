@@ -10,8 +10,89 @@ stereo/stereo_disparity_RAFT.py:46.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+# While this is on (the product's forward passes switch it on), norm -> ReLU and the
+# residual joins run as fused in-place HIP passes; off, the modules execute the
+# stock PyTorch operators (what the oracle runs).
+_FUSED = False
+
+
+@contextlib.contextmanager
+def fused_passes(on: bool = True):
+    global _FUSED
+    old, _FUSED = _FUSED, on
+    try:
+        yield
+    finally:
+        _FUSED = old
+
+
+def fused_on() -> bool:
+    return _FUSED and not torch.is_autocast_enabled()
+
+
+def _fusable(x: torch.Tensor) -> bool:
+    return fused_on() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+
+
+def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool) -> torch.Tensor:
+    """relu(norm(conv(x))) (or without the ReLU).  Fused path: the convolution runs
+    WITHOUT its bias and one in-place HIP pass applies bias + norm + ReLU -- instance
+    norm removes any per-channel constant, so the bias drops out entirely; inference
+    batch norm absorbs it into its shift.  Stock operators otherwise."""
+    if _fusable(x):
+        if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            return ops.instance_norm_relu_(y, norm.eps, relu)
+        if isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats:
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            scale, shift = _folded_batch_norm(norm, conv.bias)
+            return ops.channel_affine_relu_(y, scale, shift, relu)
+    y = norm(conv(x))
+    return torch.relu_(y) if relu else y
+
+
+def conv_act(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """relu(conv(x)); fused: bias-free convolution, then bias + ReLU in one in-place pass."""
+    if _fusable(x) and conv.bias is not None:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        ones = getattr(conv, "_vo_ones", None)
+        if ones is None or ones.device != y.device:
+            ones = torch.ones(conv.out_channels, device=y.device, dtype=torch.float32)
+            conv._vo_ones = ones
+        return ops.channel_affine_relu_(y, ones, conv.bias, True)
+    return torch.relu_(conv(x))
+
+
+def _folded_batch_norm(norm: nn.BatchNorm2d, conv_bias=None):
+    """(scale, shift) with x*scale + shift equal to the inference-mode batch norm of
+    (x + conv_bias); cached on the module and rebuilt when any tensor is modified or moved."""
+    tensors = [norm.running_mean, norm.running_var] + [t for t in (norm.weight, norm.bias, conv_bias) if t is not None]
+    key = tuple((t._version, t.data_ptr()) for t in tensors)
+    cached = getattr(norm, "_vo_folded", None)
+    if cached is None or cached[0] != key:
+        w = norm.weight if norm.weight is not None else torch.ones_like(norm.running_var)
+        b = norm.bias if norm.bias is not None else torch.zeros_like(norm.running_var)
+        scale = (w * torch.rsqrt(norm.running_var + norm.eps)).float().contiguous()
+        mean = norm.running_mean if conv_bias is None else norm.running_mean - conv_bias
+        shift = (b - mean * scale).float().contiguous()
+        cached = (key, scale, shift)
+        norm._vo_folded = cached
+    return cached[1], cached[2]
+
+
+def add_act(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """relu(x + y); in place into y (a fresh conv output) when fused."""
+    if _fusable(y) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape == y.shape:
+        return ops.add_relu_(y, x)
+    return torch.relu(x + y)
 
 
 def _norm(kind: str, planes: int) -> nn.Module:
@@ -44,11 +125,11 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
+        y = conv_norm_act(x, self.conv1, self.norm1, True)
+        y = conv_norm_act(y, self.conv2, self.norm2, True)
         if self.downsample is not None:
-            x = self.downsample(x)
-        return self.relu(x + y)
+            x = conv_norm_act(x, self.downsample[0], self.norm3, False)
+        return add_act(x, y)
 
 
 def _init_weights(module: nn.Module):
@@ -87,7 +168,7 @@ class BasicEncoder(nn.Module):
         return blocks
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = conv_norm_act(x, self.conv1, self.norm1, True)
         x = self.layer3(self.layer2(self.layer1(x)))
         return self.conv2(x)
 
@@ -124,7 +205,7 @@ class MultiBasicEncoder(nn.Module):
         return blocks
 
     def forward(self, x: torch.Tensor, num_layers: int = 3):
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = conv_norm_act(x, self.conv1, self.norm1, True)
         x = self.layer3(self.layer2(self.layer1(x)))
         out08 = [f(x) for f in self.outputs08]
         if num_layers == 1:

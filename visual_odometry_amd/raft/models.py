@@ -21,8 +21,14 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import BasicEncoder, MultiBasicEncoder
+from .layers import BasicEncoder, MultiBasicEncoder, fused_passes
 from .update import BasicMultiUpdateBlock, BasicUpdateBlock
+
+
+def _autocast(dtype):
+    """Autocast context for the conv nets (the published models' ``mixed_precision``
+    switch; the reference leaves it off, so the default is full float32)."""
+    return torch.autocast(device_type="cuda", dtype=dtype, enabled=dtype is not None)
 
 
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
@@ -71,11 +77,14 @@ class RAFTFlow(nn.Module):
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=3)
         self.cnet = BasicEncoder(output_dim=c.hidden_dim + c.context_dim, norm_fn="batch", downsample=3)
         self.update_block = BasicUpdateBlock(c.corr_levels, c.corr_radius, hidden_dim=c.hidden_dim)
+        self.amp_dtype = None            # e.g. torch.bfloat16: experiment only, not the reference's precision
 
     @torch.no_grad()
     def features(self, images: torch.Tensor) -> torch.Tensor:
         """Normalised images (B,3,H,W) -> pixel-major feature maps (B,H/8,W/8,256)."""
-        return pixel_major(self.fnet(images))
+        with _autocast(self.amp_dtype), fused_passes():
+            fmap = self.fnet(images)
+        return pixel_major(fmap)
 
     @torch.no_grad()
     def forward(self, image1, image2, iters: int = 12, flow_init=None, fmap1=None, fmap2=None,
@@ -97,8 +106,9 @@ class RAFTFlow(nn.Module):
         corr = ops.corr_volume_2d(fmap1, fmap2)
         pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
 
-        net, inp = torch.split(self.cnet(image1), [c.hidden_dim, c.context_dim], dim=1)
-        net, inp = torch.tanh(net), torch.relu(inp)
+        with _autocast(self.amp_dtype), fused_passes():
+            net, inp = torch.split(self.cnet(image1), [c.hidden_dim, c.context_dim], dim=1)
+            net, inp = torch.tanh(net), torch.relu(inp)
 
         coords0 = coords_grid(B, H8, W8, image1.device)
         coords1 = coords0.clone()
@@ -108,10 +118,11 @@ class RAFTFlow(nn.Module):
         for it in range(iters):
             window = ops.corr_lookup_2d(pyramid, coords1.contiguous(), c.corr_radius)
             flow = coords1 - coords0
-            net, raw_mask, delta = self.update_block(net, inp, window, flow, want_mask=(it == iters - 1))
-            coords1 = coords1 + delta
+            with _autocast(self.amp_dtype), fused_passes():
+                net, raw_mask, delta = self.update_block(net, inp, window, flow, want_mask=(it == iters - 1))
+            coords1 = coords1 + delta.float()
         flow_low = (coords1 - coords0).contiguous()
-        flow_up = ops.convex_upsample(flow_low, raw_mask.contiguous(), 8, mask_scale=0.25)
+        flow_up = ops.convex_upsample(flow_low, raw_mask.float().contiguous(), 8, mask_scale=0.25)
         return flow_low, flow_up
 
 
@@ -147,6 +158,7 @@ class RAFTStereo(nn.Module):
         self.context_zqr_convs = nn.ModuleList(
             [nn.Conv2d(context_dims[i], c.hidden_dims[i] * 3, 3, padding=1) for i in range(c.n_gru_layers)])
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=c.n_downsample)
+        self.amp_dtype = None
 
     @torch.no_grad()
     def forward(self, image1, image2, iters: int = 12, flow_init=None, normalized: bool = False):
@@ -160,14 +172,16 @@ class RAFTStereo(nn.Module):
             image2 = normalize_image(image2)
         B = image1.shape[0]
 
-        cnet_list = self.cnet(image1, num_layers=c.n_gru_layers)
-        both = pixel_major(self.fnet(torch.cat([image1, image2], dim=0)))
+        with _autocast(self.amp_dtype), fused_passes():
+            cnet_list = self.cnet(image1, num_layers=c.n_gru_layers)
+            both = self.fnet(torch.cat([image1, image2], dim=0))
+            net_list = [torch.tanh(x[0]) for x in cnet_list]
+            inp_list = [torch.relu(x[1]) for x in cnet_list]
+            # the GRUs' context terms do not change across iterations: convolve once
+            inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+                        for i, conv in zip(inp_list, self.context_zqr_convs)]
+        both = pixel_major(both)
         fmap1, fmap2 = both[:B], both[B:]
-        net_list = [torch.tanh(x[0]) for x in cnet_list]
-        inp_list = [torch.relu(x[1]) for x in cnet_list]
-        # the GRUs' context terms do not change across iterations: convolve once
-        inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
-                    for i, conv in zip(inp_list, self.context_zqr_convs)]
 
         corr = ops.corr_volume_1d(fmap1, fmap2)
         pyramid = ops.corr_pyramid_1d(corr, c.corr_levels)
@@ -186,12 +200,14 @@ class RAFTStereo(nn.Module):
             if c.n_gru_layers >= 2 and c.slow_fast_gru:
                 net_list = self.update_block(net_list, inp_list, iter32=c.n_gru_layers == 3, iter16=True,
                                              iter08=False, update=False)
-            net_list, raw_mask, delta = self.update_block(net_list, inp_list, window, flow,
-                                                          iter32=c.n_gru_layers == 3, iter16=c.n_gru_layers >= 2,
-                                                          want_mask=(it == iters - 1))
+            with _autocast(self.amp_dtype), fused_passes():
+                net_list, raw_mask, delta = self.update_block(net_list, inp_list, window, flow,
+                                                              iter32=c.n_gru_layers == 3, iter16=c.n_gru_layers >= 2,
+                                                              want_mask=(it == iters - 1))
+            delta = delta.float()
             delta = torch.cat([delta[:, :1], torch.zeros_like(delta[:, 1:])], dim=1)   # epipolar: no y motion
             coords1 = coords1 + delta
         flow_low = (coords1 - coords0).contiguous()
-        disparity = ops.convex_upsample(flow_low, raw_mask.contiguous(), 2 ** c.n_downsample, out_channels=1,
+        disparity = ops.convex_upsample(flow_low, raw_mask.float().contiguous(), 2 ** c.n_downsample, out_channels=1,
                                         mask_scale=0.25)
         return flow_low, disparity

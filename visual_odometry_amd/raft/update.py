@@ -13,6 +13,29 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+from .layers import conv_act, fused_on
+
+
+def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Conv2d) -> torch.Tensor:
+    """cat(convz.weight, convr.weight): z and r read the same input, so one convolution
+    with 2C output channels replaces two.  Cached; rebuilt if a weight changes or moves."""
+    key = (convz.weight._version, convz.weight.data_ptr(), convr.weight._version, convr.weight.data_ptr())
+    cached = getattr(owner, "_vo_zr_" + tag, None)
+    if cached is None or cached[0] != key:
+        cached = (key, torch.cat([convz.weight, convr.weight], dim=0).contiguous())
+        setattr(owner, "_vo_zr_" + tag, cached)
+    return cached[1]
+
+
+def _fused_gru_step(owner, tag, buf, h, C, convz, convr, convq, ctx=(None, None, None), h_copy=None):
+    """One GRU step on buf = [h | x] (B, C+X, H, W).  buf's first C channels are
+    overwritten with r*h for the q convolution; returns the new hidden state."""
+    zr = F.conv2d(buf, _merged_zr_weight(owner, tag, convz, convr), None, padding=convz.padding)
+    z = ops.gru_gates(zr, convz.bias, convr.bias, ctx[0], ctx[1], h, buf[:, :C])
+    q = F.conv2d(buf, convq.weight, None, padding=convq.padding)
+    return ops.gru_update(q, convq.bias, ctx[2], z, h, torch.empty_like(h), h_copy)
+
 
 class FlowHead(nn.Module):
     def __init__(self, input_dim: int = 128, hidden_dim: int = 256, output_dim: int = 2):
@@ -22,7 +45,7 @@ class FlowHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.conv2(self.relu(self.conv1(x)))
+        return self.conv2(conv_act(x, self.conv1))
 
 
 class SepConvGRU(nn.Module):
@@ -47,6 +70,15 @@ class SepConvGRU(nn.Module):
         return (1 - z) * h + z * q
 
     def forward(self, h, x):
+        """``x`` may be a tensor or a list of tensors that together form the input."""
+        if fused_on() and h.is_cuda and h.dtype == torch.float32:
+            parts = list(x) if isinstance(x, (list, tuple)) else [x]
+            C = h.shape[1]
+            buf = torch.cat([h] + parts, dim=1)                          # the only copy of the step
+            h = _fused_gru_step(self, "1", buf, h, C, self.convz1, self.convr1, self.convq1, h_copy=buf[:, :C])
+            return _fused_gru_step(self, "2", buf, h, C, self.convz2, self.convr2, self.convq2)
+        if isinstance(x, (list, tuple)):
+            x = torch.cat(list(x), dim=1)
         h = self._step(h, x, self.convz1, self.convr1, self.convq1)
         return self._step(h, x, self.convz2, self.convr2, self.convq2)
 
@@ -62,6 +94,9 @@ class ConvGRU(nn.Module):
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
 
     def forward(self, h, cz, cr, cq, *x_list):
+        if fused_on() and h.is_cuda and h.dtype == torch.float32:
+            buf = torch.cat([h] + list(x_list), dim=1)
+            return _fused_gru_step(self, "0", buf, h, h.shape[1], self.convz, self.convr, self.convq, (cz, cr, cq))
         x = torch.cat(x_list, dim=1)
         hx = torch.cat([h, x], dim=1)
         z = torch.sigmoid(self.convz(hx) + cz)
@@ -82,9 +117,11 @@ class FlowMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
-        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
-        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
-        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+        cor = conv_act(conv_act(corr, self.convc1), self.convc2)
+        flo = conv_act(conv_act(flow, self.convf1), self.convf2)
+        out = conv_act(torch.cat([cor, flo], dim=1), self.conv)
+        if fused_on():
+            return [out, flow]                       # the GRU concatenates once, with its other inputs
         return torch.cat([out, flow], dim=1)
 
 
@@ -100,9 +137,11 @@ class StereoMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 64, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
-        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
-        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
-        out = F.relu(self.conv(torch.cat([cor, flo], dim=1)))
+        cor = conv_act(conv_act(corr, self.convc1), self.convc2)
+        flo = conv_act(conv_act(flow, self.convf1), self.convf2)
+        out = conv_act(torch.cat([cor, flo], dim=1), self.conv)
+        if fused_on():
+            return [out, flow]                       # the GRU concatenates once, with its other inputs
         return torch.cat([out, flow], dim=1)
 
 
@@ -119,9 +158,12 @@ class BasicUpdateBlock(nn.Module):
 
     def forward(self, net, inp, corr, flow, want_mask: bool = True):
         motion = self.encoder(flow, corr)
-        net = self.gru(net, torch.cat([inp, motion], dim=1))
+        if isinstance(motion, list):
+            net = self.gru(net, [inp] + motion)
+        else:
+            net = self.gru(net, torch.cat([inp, motion], dim=1))
         delta_flow = self.flow_head(net)
-        raw_mask = self.mask(net) if want_mask else None      # caller scales by 0.25
+        raw_mask = self.mask[2](conv_act(net, self.mask[0])) if want_mask else None      # caller scales by 0.25
         return net, raw_mask, delta_flow
 
 
@@ -163,12 +205,13 @@ class BasicMultiUpdateBlock(nn.Module):
                 net[1] = self.gru16(net[1], *(inp[1]), pool2x(net[0]))
         if iter08:
             motion = self.encoder(flow, corr)
+            motion = motion if isinstance(motion, list) else [motion]
             if self.n_gru_layers > 1:
-                net[0] = self.gru08(net[0], *(inp[0]), motion, interp(net[1], net[0]))
+                net[0] = self.gru08(net[0], *(inp[0]), *motion, interp(net[1], net[0]))
             else:
-                net[0] = self.gru08(net[0], *(inp[0]), motion)
+                net[0] = self.gru08(net[0], *(inp[0]), *motion)
         if not update:
             return net
         delta_flow = self.flow_head(net[0])
-        raw_mask = self.mask(net[0]) if want_mask else None   # caller scales by 0.25
+        raw_mask = self.mask[2](conv_act(net[0], self.mask[0])) if want_mask else None   # caller scales by 0.25
         return net, raw_mask, delta_flow
