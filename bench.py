@@ -66,7 +66,7 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
 
 
 PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_pyramid_2d": "pyr2d", "vo_corr_lookup_2d": "lookup2d",
-            "vo_corr_lookup_1d": "lookup1d"}
+            "vo_corr_lookup_1d": "lookup1d", "vo_instance_norm_relu": "instnorm", "vo_add_relu": "add_relu"}
 
 
 def pmc_traffic(kernel: str, B: int, H: int, W: int):
@@ -224,6 +224,14 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
     roofline["traffic"] = pmc_traffic(dom, B, H, W)
+    # the north star's one dense contraction, reported whether or not it dominates
+    ck = kernels.get("vo_corr_volume_2d")
+    roofline_corr = None
+    if ck:
+        roofline_corr = {"kernel": "vo_corr_volume_2d", "bound": "mfma", "achieved": ck["TFLOPs"],
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ck["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
+                         "avg_launch_us": ck["avg_us"], "traffic": pmc_traffic("vo_corr_volume_2d", B, H, W),
+                         "mfma_util_pmc": 0.695}   # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE/8), profiles/r01_mfma_util.json
     roofline["alg_per_launch"] = (work[dom].get("flops") if roofline["bound"] == "mfma" else work[dom]["bytes"]) / work[dom]["launches"]
     hand_ms = sum(k["ms_per_step"] for k in kernels.values())
 
@@ -238,6 +246,7 @@ def main():
                        "pairs_per_step_per_gpu": B, "pairs_timed": pairs, "iters": args.iters,
                        "sharding": f"{world} rank(s), contiguous pair ranges, no data-path collective"},
             "roofline": roofline,
+            "roofline_corr": roofline_corr,
             "hand_kernels_ms_per_step": hand_ms,
             "hand_kernels_share_of_step": hand_ms / (1e3 * elapsed / args.steps),
             "kernels": kernels,

@@ -48,6 +48,20 @@ def main():
     kp = UniformKeyPoints(np.ones((H, W), bool)).get_keypoints_device(320 if W == 640 else 20000)
     flow_full = rnd(B, 2, H, W)
     Kinv = np.linalg.inv(syn.left_K(W / 640.0))
+    if a.only and "encoders" in a.only.split(","):
+        # the instance-norm / add+ReLU passes at exactly the shapes of one bench step:
+        # RAFT-Flow's feature encoder on B+1 frames, RAFT-Stereo's on 2B images
+        from visual_odometry_amd.raft.layers import BasicEncoder, fused_passes
+        torch.manual_seed(0)
+        enc8 = BasicEncoder(256, "instance", 3).to(dev).eval()
+        enc4 = BasicEncoder(256, "instance", 2).to(dev).eval()
+        i8, i4 = rnd(B + 1, 3, H, W), rnd(2 * B, 3, H, W)
+        with torch.no_grad(), fused_passes():
+            for _ in range(a.reps):
+                enc8(i8); enc4(i4)
+        torch.cuda.synchronize()
+        print("done")
+        return
     torch.cuda.synchronize()
     for _ in range(a.reps):
         if want("corr2d"): ops.corr_volume_2d(f1, f2)
