@@ -61,6 +61,9 @@ int vo_instance_norm_relu(float* x, int64_t planes, int64_t hw, float eps, int r
 int vo_channel_affine_relu(float* x, const float* scale, const float* shift, int64_t batch,
                            int C, int64_t hw, int relu, void* stream);
 int vo_add_relu(float* a, const float* b, int64_t n, void* stream);
+/* (planes,h,w) -> (planes,H,W) bilinear, corner-aligned (align_corners=True): the
+ * inter-level state exchange of RAFT-Stereo's multi-level GRU. */
+int vo_resize_bilinear(const float* in, float* out, int64_t planes, int h, int w, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Gate arithmetic of the convolutional GRUs (SepConvGRU of RAFT, ConvGRU of

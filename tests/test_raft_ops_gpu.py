@@ -359,3 +359,16 @@ def test_fused_gru_steps_match_stock_operators(vo):
         for x, y in zip(a[0], b[0]):
             assert (x - y).abs().max().item() < 1e-4
         assert (a[1] - b[1]).abs().max().item() < 1e-3 and (a[2] - b[2]).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("shape,size", [((2, 5, 6, 10), (12, 20)), ((1, 64, 60, 80), (120, 160)), ((1, 3, 7, 5), (9, 13)),
+                                        ((1, 2, 1, 4), (1, 9)), ((2, 3, 8, 8), (8, 8))])
+def test_resize_bilinear_matches_interpolate(vo, shape, size):
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(*shape, seed=70).to(DEV)
+    got = ops.resize_bilinear(x, size)
+    want = Fn.interpolate(x, size, mode="bilinear", align_corners=True)
+    # the source coordinate scale*x may differ by one float ulp (fused vs separate multiply):
+    # up to ~8e-6 of a pixel at these widths, times the local slope of the data
+    assert got.shape == want.shape and (got - want).abs().max().item() < 1e-4

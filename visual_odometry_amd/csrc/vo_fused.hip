@@ -94,7 +94,49 @@ __global__ __launch_bounds__(256) void add_relu_kernel(float* __restrict__ a, co
     for (int64_t i = (n4 << 2) + t; i < n; i += stride) a[i] = fmaxf(a[i] + b[i], 0.0f);
 }
 
+// Bilinear resize with corner-aligned sampling (F.interpolate(mode="bilinear",
+// align_corners=True)): the inter-level exchange of RAFT-Stereo's multi-level GRU.
+// One lane per 4 output pixels of a row; source rows are re-read from L2.
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total,
+                                                     int h, int w, int H, int W, float sy, float sx) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int wq = (W + 3) >> 2;
+    const int xq = (int)(t % wq);
+    const int y = (int)((t / wq) % H);
+    const int64_t plane = t / ((int64_t)wq * H);
+    const float fy = sy * (float)y;
+    const int y0 = min((int)fy, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+    const float* r0 = in + (plane * h + y0) * (int64_t)w;
+    const float* r1 = in + (plane * h + y1) * (int64_t)w;
+    float* o = out + (plane * H + y) * (int64_t)W + 4 * xq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = 4 * xq + i;
+        if (x >= W) break;
+        const float fx = sx * (float)x;
+        const int x0 = min((int)fx, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+        o[i] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+    }
+}
+
 }  // namespace
+
+extern "C" int vo_resize_bilinear(const float* in, float* out, int64_t planes, int h, int w, int H, int W,
+                                  void* stream) {
+    VO_REQUIRE(in && out, "vo_resize_bilinear: null pointer");
+    VO_REQUIRE(planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "vo_resize_bilinear: bad sizes");
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    const int64_t total = planes * H * ((W + 3) / 4);
+    const int64_t blocks = vo_ceil_div(total, 256);
+    if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_resize_bilinear: grid too large");
+    resize_kernel<<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(in, out, total, h, w, H, W, sy, sx);
+    VO_CHECK_LAUNCH("vo_resize_bilinear");
+    return VO_OK;
+}
 
 extern "C" int vo_instance_norm_relu(float* x, int64_t planes, int64_t hw, float eps, int relu, void* stream) {
     VO_REQUIRE(x, "vo_instance_norm_relu: null pointer");

@@ -100,6 +100,16 @@ def add_relu_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return a
 
 
+def resize_bilinear(x: torch.Tensor, size) -> torch.Tensor:
+    """(B,C,h,w) -> (B,C,H,W), bilinear with align_corners=True."""
+    B, C, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    _call("vo_resize_bilinear", _dev(x, "x", torch.float32), out.data_ptr(), B * C, h, w, H, W, _stream(),
+          nbytes=4 * (x.numel() + out.numel()))
+    return out
+
+
 def _slice(t, name: str):
     """A (B,C,H,W) float32 GPU tensor whose (C,H,W) block is dense but whose batch items
     may be further apart (a channel slice of a bigger NCHW tensor) -> (ptr, batch stride)."""
