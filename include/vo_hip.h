@@ -181,6 +181,27 @@ int vo_pair_correspondences(const double* kp, int64_t kp_batch_stride,
                             uint8_t* weight_out, int32_t* n_in_range_out,
                             int batch, int N, int H, int W, void* stream);
 
+/* Keypoints3DXform.to_2d -- keypoints/keypoints_3d.py:51-70.  points (n,3) float64,
+ * K_host = 9 doubles on the host; uv_out (n,2) float64, keep_out (n) uint8: 0 where
+ * Z <= 0 (the reference DROPS those rows; the caller compacts with keep_out). */
+int vo_keypoints_to_2d(const double* points, const double* K_host, double* uv_out, uint8_t* keep_out,
+                       int64_t n, void* stream);
+
+/* Multi-frame keypoint tracks -- the loop of test_keypoints_flow.py:235-310 over
+ * `frames` consecutive frames whose first has sequence index first_index.
+ * depth (frames,H,W), flow (frames-1,2,H,W) with flow[i]: frame i -> i+1;
+ * grid_kp (N,2) float64 = the seeding grid.  Iteration i seeds (grid points with
+ * depth[i] > 0) when (first_index+i) % k == 0, at i == 0, or when fewer than
+ * min_points rows survived iteration i-1 (:280); otherwise it advances the surviving
+ * rows with compute_3d_flow(depth[i], depth[i+1], flow[i]) and re-projects them with
+ * to_2d.  Outputs, slot j = grid point j of the latest seeding: tracks_out
+ * (frames-1,N,3) float64 (x, y, Z), zeros for dead slots; alive_out (frames-1,N)
+ * uint8; reseeded_out (frames-1) uint8.  One workgroup per k-aligned segment. */
+int vo_track_keypoints(const double* grid_kp, const float* depth, const float* flow,
+                       const double* K_host, const double* Kinv_host, int first_index, int k,
+                       int min_points, double* tracks_out, uint8_t* alive_out, uint8_t* reseeded_out,
+                       int frames, int N, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------------------
  * CameraSvdXform.compute_camera_xform -- camera/camera_svd_xform.py:18-48,
  * batched: one 64-lane wavefront per pair.

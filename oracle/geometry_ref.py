@@ -295,3 +295,51 @@ def compose_trajectory(T_rel, skipped=None) -> np.ndarray:
             G = G @ T_rel[i]
         out[i] = G
     return out
+
+
+# --------------------------------------------------------------------------
+# multi-frame keypoint tracks                           test_keypoints_flow.py
+# --------------------------------------------------------------------------
+
+def track_keypoints(grid_kp, depth, flow, K, K_inv, k=25, min_points=4, first_index=0):
+    """test_keypoints_flow.py:235-310, the multi-frame mode, for frames
+    ``first_index .. first_index + F - 1`` with depth (F,H,W) and flow (F-1,2,H,W)
+    (flow[i]: frame i -> i+1).
+
+    Iteration i either SEEDS (:261-275 when ``i % k == 0`` or nothing is tracked
+    yet; :280-291 when fewer than ``min_points`` rows went into the step) -- grid
+    points lifted with depth[i], those with Z > 0 kept -- or STEPS (:277-296):
+    compute_3d_flow(current, depth[i], depth[i+1], flow[i]), keep the valid rows,
+    re-project them with to_2d.  The reference's quirks are kept: a seeding
+    iteration applies no flow, so points seeded in frame i are used as frame-(i+1)
+    positions by the next step, and the ``< 4`` test looks at the row count BEFORE
+    the validity mask is applied (:280).
+
+    Tracks are reported in fixed slots (slot j = grid point j of the latest
+    seeding): returns (tracks (F-1,N,3) = (x, y, Z) appended at each iteration,
+    zeros for dead slots; alive (F-1,N) bool; reseeded (F-1,) bool)."""
+    grid_kp = np.asarray(grid_kp)
+    F, N = depth.shape[0], grid_kp.shape[0]
+    tracks = np.zeros((max(F - 1, 0), N, 3))
+    alive = np.zeros((max(F - 1, 0), N), dtype=bool)
+    reseeded = np.zeros(max(F - 1, 0), dtype=bool)
+    cur_kp, cur_slots = None, None
+    for i in range(F - 1):
+        seed = (first_index + i) % k == 0 or cur_kp is None or cur_kp.shape[0] < min_points
+        if seed:
+            p = lift_to_3d(grid_kp, depth[i], K_inv)
+            keep = p[:, 2] > 0
+            cur_slots = np.nonzero(keep)[0]
+            cur_kp = grid_kp[keep]
+            tracks[i, cur_slots, 0:2] = cur_kp
+            tracks[i, cur_slots, 2] = p[keep, 2]
+        else:
+            p2, ok = flow_3d(cur_kp, depth[i], depth[i + 1], flow[i], K_inv)
+            p2 = p2[ok]
+            cur_slots = cur_slots[ok]
+            cur_kp = project_to_2d(p2, K).reshape(-1, 2)
+            tracks[i, cur_slots, 0:2] = cur_kp
+            tracks[i, cur_slots, 2] = p2[:, 2]
+        alive[i, cur_slots] = True
+        reseeded[i] = seed
+    return tracks, alive, reseeded

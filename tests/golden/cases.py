@@ -145,3 +145,23 @@ def trajectory_files(directory, seed=77, n_images=12, n_gt=400):
             f.write(f"{i} {float(t)!r} img/image_0_{i}.png\n")
     computed = rng.uniform(-1, 1, (n_images + 2, 3))     # two more poses than images
     return imp, gtp, computed
+
+
+def track_case(seed=41, frames=14, h=120, w=160, n=48):
+    """A short sequence for the multi-frame keypoint tracks: per-pixel random flow
+    (so re-projected positions are fractional), depth maps with dead patches (tracks
+    die), and one frame whose flow throws every point out of the image (the row
+    count drops below 4 and the next iteration re-seeds).  Returns
+    (grid keypoints, depth (F,h,w), flow (F-1,2,h,w), K)."""
+    from oracle.geometry_ref import uniform_keypoints
+    rng = np.random.default_rng(seed)
+    K = syn.left_K(0.25)
+    kp = uniform_keypoints(np.ones((h, w), bool), n)
+    depth = rng.uniform(0.5, 12.0, (frames, h, w)).astype(np.float32)
+    for f in range(frames):
+        for _ in range(6):
+            y, x = int(rng.integers(0, h - 20)), int(rng.integers(0, w - 20))
+            depth[f, y:y + 20, x:x + 20] = 0.0 if rng.random() < 0.7 else -1.0
+    flow = rng.normal(0.0, 2.5, (frames - 1, 2, h, w)).astype(np.float32)
+    flow[8] += 1000.0
+    return kp, depth, flow, K

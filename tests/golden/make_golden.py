@@ -145,6 +145,41 @@ def main():
          matched_est=np.array([m[0] for m in matched]), positions_skip7=pos, transforms_skip20=np.array(xf),
          quat_R=data_utils.quaternion_to_rotation_matrix(0.3, -0.2, 0.9, -0.4), in_sum=cases.checksum(computed))
 
+    # G9 multi-frame keypoint tracks: the loop of test_keypoints_flow.py:235-310 driven
+    # with the reference's own classes (the script itself needs cv2 and a dataset) ----
+    for k_seg, first in ((5, 0), (25, 0), (4, 3)):
+        kp0, depth, flow, K = cases.track_case()
+        F, N = depth.shape[0], kp0.shape[0]
+        h, w = depth.shape[1:]
+        cam = _Cam(K)
+        mask = np.ones((h, w), bool)
+        pts_src, xform = UniformKeyPoints(mask), Keypoints3DXform(cam)
+        kf = Keypoints3DFlow(cam, xform, mask)
+        tracks = np.zeros((F - 1, N, 3)); alive = np.zeros((F - 1, N), bool); reseeded = np.zeros(F - 1, bool)
+
+        def seed_tracks(i):
+            new_kp = pts_src.get_keypoints(None, max_number=48)
+            assert np.array_equal(new_kp, kp0)
+            p3 = xform.to_3d(new_kp, depth[i])
+            ok = p3[:, 2] > 0
+            return new_kp[ok], p3[ok], np.nonzero(ok)[0]
+
+        cur2d = cur3d = slots = None
+        for i in range(F - 1):
+            if (first + i) % k_seg == 0 or cur2d is None:
+                cur2d, cur3d, slots = seed_tracks(i); reseeded[i] = True
+            else:
+                new3d, valid = kf.compute_3d_flow(cur2d, depth[i], depth[i + 1], flow[i])
+                if new3d.shape[0] < 4:
+                    cur2d, cur3d, slots = seed_tracks(i); reseeded[i] = True
+                else:
+                    cur3d = new3d[valid]
+                    cur2d = xform.to_2d(cur3d).reshape(-1, 2)
+                    slots = slots[valid]
+            tracks[i, slots, 0:2] = cur2d; tracks[i, slots, 2] = cur3d[:, 2]; alive[i, slots] = True
+        save(f"g9_tracks_k{k_seg}_f{first}", tracks=tracks, alive=alive, reseeded=reseeded,
+             in_sum=cases.checksum(kp0, depth, flow, K))
+
 
 if __name__ == "__main__":
     main()

@@ -236,3 +236,60 @@ def test_ransac_matches_oracle_with_same_triples(vo):
     Ql = Pl @ Rl.T + 0.1
     Tl, nl = ops.ransac_kabsch_batch(torch.from_numpy(Pl).to(dev), torch.from_numpy(Ql).to(dev), None, 0.05, 64, seed=3)
     assert int(nl.min()) == 19928 and rot_angle(Tl[0, :3, :3].cpu().numpy(), Rl) < 1e-9
+
+
+def test_to_2d_drops_nonpositive_depth(vo):
+    from visual_odometry_amd.geometry import HipKeypoints3DXform
+    K = cases.K_for(640)
+    xform = HipKeypoints3DXform(_Cam(K))
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-2, 2, (257, 3)); pts[:, 2] = rng.uniform(-1, 8, 257); pts[5, 2] = 0.0
+    got = xform.to_2d(pts)
+    want = ref.project_to_2d(pts, K)
+    assert got.shape == want.shape and got.shape[0] == int((pts[:, 2] > 0).sum())
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-12)
+    assert xform.to_2d(np.zeros((0, 3))).shape == (0,)
+    assert xform.to_2d(np.array([[1.0, 1.0, -1.0]])).shape == (0,)
+
+
+@pytest.mark.parametrize("k_seg,first", [(5, 0), (25, 0), (4, 3)])
+def test_keypoint_tracks_match_reference(vo, k_seg, first):
+    from visual_odometry_amd.geometry import HipKeypointTracker
+    g = golden(f"g9_tracks_k{k_seg}_f{first}")
+    kp, depth, flow, K = cases.track_case()
+    tracker = HipKeypointTracker(_Cam(K), kp, k=k_seg)
+    tracks, alive, reseeded = tracker.track_batch(torch.from_numpy(depth).cuda(), torch.from_numpy(flow).cuda(), first)
+    tracks, alive, reseeded = tracks.cpu().numpy(), alive.cpu().numpy(), reseeded.cpu().numpy()
+    assert np.array_equal(alive, g["alive"]) and np.array_equal(reseeded, g["reseeded"])
+    np.testing.assert_allclose(tracks, g["tracks"], rtol=1e-12, atol=1e-10)
+    lists, start_z = HipKeypointTracker.as_track_lists(tracks, alive, reseeded, 3)
+    assert len(lists) == int(alive[3].sum()) and all(len(t) == 4 - max(i for i in range(4) if reseeded[i]) for t in lists)
+    assert all(z > 0 for z in start_z)
+
+
+def test_keypoint_tracks_dense_grid_and_sharding(vo):
+    """A dense grid (more slots than lanes) at full resolution against the oracle, and the
+    same sequence tracked as two k-aligned shards: segments are independent."""
+    from visual_odometry_amd.geometry import HipKeypointTracker
+    rng = np.random.default_rng(8)
+    h, w, F, k = 240, 320, 13, 4
+    K = syn.left_K(0.5)
+    kp = ref.uniform_keypoints(np.ones((h, w), bool), 3000)
+    depth = rng.uniform(0.5, 12.0, (F, h, w)).astype(np.float32)
+    depth[:, 50:90, 100:180] = 0.0
+    flow = rng.normal(0, 1.5, (F - 1, 2, h, w)).astype(np.float32)
+    want = ref.track_keypoints(kp, depth, flow, K, np.linalg.inv(K), k=k)
+    tracker = HipKeypointTracker(_Cam(K), kp, k=k)
+    d, f = torch.from_numpy(depth).cuda(), torch.from_numpy(flow).cuda()
+    got = [t.cpu().numpy() for t in tracker.track_batch(d, f)]
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-12, atol=1e-10)
+    a = [t.cpu().numpy() for t in tracker.track_batch(d[:9], f[:8], 0)]
+    b = [t.cpu().numpy() for t in tracker.track_batch(d[8:], f[8:], 8)]
+    for i in range(3):
+        assert np.array_equal(np.concatenate([a[i], b[i]]), got[i])
+    # degenerate sizes
+    one = tracker.track_batch(d[:1], f[:0])
+    assert one[0].shape == (0, kp.shape[0], 3)
+    with pytest.raises(ValueError):
+        tracker.track_batch(d, f[:-2])

@@ -112,3 +112,15 @@ def test_ransac_recovers_motion_with_outliers():
     assert rot_angle(Rr, R) < 5e-3 and np.abs(tr - t).max() < 1e-2
     with pytest.raises(ValueError):
         ref.ransac_kabsch(P[:2], Q[:2])
+
+
+@pytest.mark.parametrize("k_seg,first", [(5, 0), (25, 0), (4, 3)])
+def test_g9_keypoint_tracks(k_seg, first):
+    g = golden(f"g9_tracks_k{k_seg}_f{first}")
+    kp, depth, flow, K = cases.track_case()
+    assert cases.checksum(kp, depth, flow, K) == float(g["in_sum"])
+    tracks, alive, reseeded = ref.track_keypoints(kp, depth, flow, K, np.linalg.inv(K), k=k_seg, first_index=first)
+    assert np.array_equal(alive, g["alive"]) and np.array_equal(reseeded, g["reseeded"])
+    np.testing.assert_allclose(tracks, g["tracks"], rtol=1e-12, atol=1e-10)
+    # the fixture exercises dying tracks and the "fewer than 4 rows" re-seed
+    assert g["alive"].sum(1).min() < 4 and g["reseeded"][9] and 0 < g["alive"][3].sum() < g["alive"][0].sum()

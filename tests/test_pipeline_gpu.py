@@ -110,3 +110,35 @@ def test_high_resolution_dense_grid(vo):
         R, t = ref.kabsch(P1[wgt], P2[wgt], np.array(syn.CAMERA_OFFSET))
         np.testing.assert_allclose(T[0, :3, :3].cpu().numpy(), R, atol=1e-8)
         np.testing.assert_allclose(T[0, :3, 3].cpu().numpy(), t, atol=1e-8)
+
+
+def test_keypoint_tracks_through_the_pipeline(vo):
+    """Depth and flow from the networks, tracks from the one-launch tracker: equal to the
+    oracle's frame-by-frame loop on the same maps, and to two k-aligned shards."""
+    from visual_odometry_amd.pipeline import shard_segments
+    H, W, F, k = 96, 128, 8, 3
+    pipe = _vo(H, W)
+    left, right = syn.stereo_sequence(12, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    from visual_odometry_amd.geometry import HipKeypointTracker
+    kp = pipe.pts_src.get_keypoints(None, 60)
+    K = syn.left_K(W / 640.0)
+    depth, flow = pipe.depth_maps(l, r), pipe.flows(l)
+    tracker = HipKeypointTracker(pipe._cam, kp, k=k)
+    tracks, alive, reseeded = [t.cpu().numpy() for t in tracker.track_batch(depth, flow)]
+    want = ref.track_keypoints(kp, depth.cpu().numpy(), flow.cpu().numpy(), K, np.linalg.inv(K), k=k)
+    assert np.array_equal(alive, want[1]) and np.array_equal(reseeded, want[2]) and alive.any()
+    np.testing.assert_allclose(tracks, want[0], rtol=1e-12, atol=1e-10)
+    # the one-call entry runs the networks again (MIOpen may pick another solver: rounding-level changes)
+    again = [t.cpu().numpy() for t in pipe.track_keypoints(l, r, k=k, max_keypoints=60)]
+    assert (again[1] != alive).mean() < 0.02 and np.array_equal(again[2], reseeded)
+    assert np.abs(again[0] - tracks)[again[1] & alive].max() < 1e-2
+    parts = []
+    for rank in range(2):
+        s, e = shard_segments(F - 1, k, rank, 2)
+        parts.append(pipe.track_keypoints(l[s:e + 1], r[s:e + 1], k=k, max_keypoints=60, first_index=s))
+    got_alive = torch.cat([p[1] for p in parts]).cpu().numpy()
+    # different batch sizes change MIOpen's reduction order by rounding only
+    assert (got_alive != alive).mean() < 0.02
+    same = got_alive & alive
+    assert np.abs(torch.cat([p[0] for p in parts]).cpu().numpy() - tracks)[same].max() < 1e-2

@@ -9,7 +9,7 @@ import torch.multiprocessing as mp
 
 from oracle import geometry_ref as ref
 from visual_odometry_amd import synthetic as syn
-from visual_odometry_amd.pipeline import compose_trajectory, gather_poses, shard_pairs, write_trajectory
+from visual_odometry_amd.pipeline import compose_trajectory, gather_poses, shard_pairs, shard_segments, write_trajectory
 
 
 def _poses(n, seed=0):
@@ -33,6 +33,13 @@ def test_shard_pairs_partition(n, world):
         assert covered == list(range(n))
     sizes = [e - s for s, e in blocks]
     assert max(sizes) == -(-n // world) if n else max(sizes) == 0
+
+
+@pytest.mark.parametrize("n,k,world", [(99, 25, 2), (100, 25, 8), (7, 3, 2), (0, 5, 4), (24, 25, 3)])
+def test_shard_segments_cut_at_seeding_frames(n, k, world):
+    blocks = [shard_segments(n, k, r, world) for r in range(world)]
+    assert [i for s, e in blocks for i in range(s, e)] == list(range(n))
+    assert all(s % k == 0 or s == n for s, _ in blocks)
 
 
 def test_compose_matches_oracle_and_skips():

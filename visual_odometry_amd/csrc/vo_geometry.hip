@@ -174,6 +174,86 @@ __global__ __launch_bounds__(256) void flow3d_kernel(const double* __restrict__ 
     }
 }
 
+// keypoints/keypoints_3d.py:62-68: (u, v) = (K [X/Z, Y/Z, 1])_{xy}; rows with Z <= 0 have no image.
+__device__ __forceinline__ bool project_point(double X, double Y, double Z, const Mat3& K, double& u, double& v) {
+#pragma clang fp contract(off)
+    if (Z <= 0.0) { u = 0.0; v = 0.0; return false; }
+    const double xn = X / Z, yn = Y / Z;
+    u = (K.m[0] * xn + K.m[1] * yn) + K.m[2];
+    v = (K.m[3] * xn + K.m[4] * yn) + K.m[5];
+    return true;
+}
+
+__global__ __launch_bounds__(256) void to2d_kernel(const double* __restrict__ pts, Mat3 K, double* __restrict__ uv,
+                                                   uint8_t* __restrict__ keep, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double u, v;
+    const bool ok = project_point(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], K, u, v);
+    uv[2 * i] = u; uv[2 * i + 1] = v;
+    keep[i] = ok ? 1 : 0;
+}
+
+// Multi-frame keypoint tracks (test_keypoints_flow.py:235-310).  One workgroup per
+// SEGMENT of iterations between two scheduled seedings; inside it the iterations are
+// sequential (each consumes the previous one's re-projected positions) and the
+// keypoint slots run across the lanes.  Slot j is always handled by the same lane,
+// so the only cross-lane traffic is the per-iteration count of rows that decides
+// the "fewer than min_points rows: seed again" rule (:280).
+__global__ __launch_bounds__(256) void track_kernel(const double* __restrict__ grid_kp, const float* __restrict__ depth,
+                                                    const float* __restrict__ flow, Mat3 K, Mat3 Ki, int first_index,
+                                                    int k, int min_points, double* __restrict__ tracks,
+                                                    uint8_t* __restrict__ alive, uint8_t* __restrict__ reseeded,
+                                                    int T, int N, int H, int W) {
+    __shared__ int wave_count[4];
+    const int lead = (k - first_index % k) % k;               // iterations before the first scheduled seeding
+    int lo, hi;
+    if (lead > 0) {
+        if (blockIdx.x == 0) { lo = 0; hi = min(lead, T); }
+        else { lo = lead + ((int)blockIdx.x - 1) * k; hi = min(lo + k, T); }
+    } else { lo = (int)blockIdx.x * k; hi = min(lo + k, T); }
+    const int64_t hw = (int64_t)H * W;
+    int rows = 0;                                              // rows that entered the previous iteration's result
+    for (int i = lo; i < hi; ++i) {
+        const bool seed = (i == lo) || (rows < min_points);
+        const float* d1m = depth + (int64_t)i * hw;
+        int mine = 0;
+        for (int j = threadIdx.x; j < N; j += blockDim.x) {
+            const int64_t o = (int64_t)i * N + j;
+            double x = 0.0, y = 0.0, z = 0.0;
+            bool a = false;
+            if (seed) {
+                x = grid_kp[2 * j]; y = grid_kp[2 * j + 1];
+                const float d = depth_at(d1m, x, y, H, W);
+                a = d > 0.0f;                                  // :266 keeps Z > 0
+                z = (double)d;
+            } else if (alive[o - N]) {
+                const double px = tracks[3 * (o - N)], py = tracks[3 * (o - N) + 1];
+                const Warp2D w = warp_point(px, py, flow + (int64_t)i * 2 * hw, H, W);
+                const float d1 = depth_at(d1m, px, py, H, W);
+                const float d2 = depth_at(d1m + hw, w.nx, w.ny, H, W);
+                if (w.valid && d1 > 0.0f && d2 > 0.0f) {
+                    double X, Y, Z;
+                    lift_point(w.nx, w.ny, d2, Ki, X, Y, Z);
+                    a = project_point(X, Y, Z, K, x, y);
+                    z = Z;
+                }
+            }
+            if (!a) { x = 0.0; y = 0.0; z = 0.0; }
+            tracks[3 * o] = x; tracks[3 * o + 1] = y; tracks[3 * o + 2] = z;
+            alive[o] = a ? 1 : 0;
+            mine += a ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, VO_WAVE);
+        __syncthreads();                                       // previous iteration's reads of wave_count are done
+        if ((threadIdx.x & (VO_WAVE - 1)) == 0) wave_count[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        rows = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+        if (threadIdx.x == 0) reseeded[i] = seed ? 1 : 0;
+    }
+}
+
 Mat3 load_mat3(const double* host9) {
     Mat3 m;
     for (int i = 0; i < 9; ++i) m.m[i] = host9[i];
@@ -266,5 +346,38 @@ extern "C" int vo_pair_correspondences(const double* kp, int64_t kp_batch_stride
                                                                max_dz, p1_out, p2_out, weight_out,
                                                                n_in_range_out, N, H, W);
     VO_CHECK_LAUNCH("vo_pair_correspondences");
+    return VO_OK;
+}
+
+extern "C" int vo_keypoints_to_2d(const double* points, const double* K_host, double* uv_out, uint8_t* keep_out,
+                                  int64_t n, void* stream) {
+    VO_REQUIRE(n >= 0, "vo_keypoints_to_2d: n=%lld < 0", (long long)n);
+    if (n == 0) return VO_OK;
+    VO_REQUIRE(points && K_host && uv_out && keep_out, "vo_keypoints_to_2d: null pointer");
+    const int64_t blocks = vo_ceil_div(n, 256);
+    if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_keypoints_to_2d: too many points");
+    to2d_kernel<<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(points, load_mat3(K_host), uv_out, keep_out, n);
+    VO_CHECK_LAUNCH("vo_keypoints_to_2d");
+    return VO_OK;
+}
+
+extern "C" int vo_track_keypoints(const double* grid_kp, const float* depth, const float* flow, const double* K_host,
+                                  const double* Kinv_host, int first_index, int k, int min_points, double* tracks_out,
+                                  uint8_t* alive_out, uint8_t* reseeded_out, int frames, int N, int H, int W,
+                                  void* stream) {
+    VO_REQUIRE(frames >= 1 && N >= 0 && H > 0 && W > 0, "vo_track_keypoints: bad sizes frames=%d N=%d H=%d W=%d",
+               frames, N, H, W);
+    VO_REQUIRE(k >= 1 && first_index >= 0 && min_points >= 0, "vo_track_keypoints: k=%d first_index=%d min_points=%d",
+               k, first_index, min_points);
+    const int T = frames - 1;
+    if (T == 0) return VO_OK;
+    VO_REQUIRE(reseeded_out && K_host && Kinv_host, "vo_track_keypoints: null pointer");
+    VO_REQUIRE(N == 0 || (grid_kp && depth && flow && tracks_out && alive_out), "vo_track_keypoints: null pointer");
+    const int lead = (k - first_index % k) % k;
+    const int segments = lead >= T ? 1 : (lead > 0 ? 1 : 0) + (int)vo_ceil_div(T - lead, k);
+    track_kernel<<<dim3((unsigned)segments), dim3(256), 0, vo_stream(stream)>>>(
+        grid_kp, depth, flow, load_mat3(K_host), load_mat3(Kinv_host), first_index, k, min_points, tracks_out, alive_out,
+        reseeded_out, T, N, H, W);
+    VO_CHECK_LAUNCH("vo_track_keypoints");
     return VO_OK;
 }

@@ -131,16 +131,17 @@ class HipKeypoints3DXform(Keypoints3DInterface):
 
     def to_2d(self, points_3D: np.ndarray) -> np.ndarray:
         """Pinhole projection; rows with Z <= 0 are dropped, so the result can be
-        shorter than the input (keypoints/keypoints_3d.py:61-70).  Only the viewers
-        call this, so it stays on the host."""
+        shorter than the input (keypoints/keypoints_3d.py:61-70)."""
         pts = np.asarray(points_3D, dtype=np.float64).reshape(-1, 3)
-        pts = pts[pts[:, 2] > 0]
         if pts.shape[0] == 0:
             return np.array([])
-        K = np.asarray(self.camera_params.K, dtype=np.float64)
-        xn = pts[:, 0] / pts[:, 2]; yn = pts[:, 1] / pts[:, 2]
-        return np.stack([K[0, 0] * xn + K[0, 1] * yn + K[0, 2],
-                         K[1, 0] * xn + K[1, 1] * yn + K[1, 2]], axis=1)
+        uv, keep = self.to_2d_batch(_to_gpu(pts, np.float64))
+        return uv[keep].cpu().numpy() if bool(keep.any()) else np.array([])
+
+    def to_2d_batch(self, points: torch.Tensor):
+        """(...,3) float64 GPU points -> (uv (...,2) float64, keep (...) bool); nothing is
+        dropped, keep marks the rows the reference would return."""
+        return ops.keypoints_to_2d(points, self.camera_params.K)
 
 
 class HipKeypoints3DFlow(Keypoints3DFlowInterface):
@@ -174,6 +175,41 @@ class HipKeypoints3DFlow(Keypoints3DFlowInterface):
         pairs: P1, P2 (B,N,3) f64, weight (B,N) uint8, n_in_range (B) int32."""
         return ops.pair_correspondences(keypoints, depth1, depth2, flow, self.K_inv,
                                         min_depth, max_depth, max_dz)
+
+
+class HipKeypointTracker:
+    """The multi-frame mode of test_keypoints_flow.py:235-310 for a whole chunk of frames
+    in one launch: seed the uniform grid every ``k`` frames (and whenever fewer than
+    ``min_points`` rows are left), advance the survivors through flow and depth, and
+    re-project them.  Segments between seedings are independent, so a sequence splits
+    across devices at multiples of ``k`` without any exchange."""
+
+    def __init__(self, camera_params, keypoints: np.ndarray, k: int = 25, min_points: int = 4):
+        self.K = np.asarray(camera_params.K, dtype=np.float64)
+        self.K_inv = np.linalg.inv(self.K)
+        self.k, self.min_points = int(k), int(min_points)
+        self.keypoints = np.asarray(keypoints).astype(np.float64).reshape(-1, 2)
+        self._kp_dev = None
+
+    def track_batch(self, depth: torch.Tensor, flow: torch.Tensor, first_index: int = 0):
+        """depth (F,H,W) float32 and flow (F-1,2,H,W) float32 GPU tensors (flow[i]: frame i
+        -> i+1) -> tracks (F-1,N,3) float64 (x, y, Z), alive (F-1,N) bool, reseeded (F-1) bool."""
+        if self._kp_dev is None or self._kp_dev.device != depth.device:
+            self._kp_dev = torch.from_numpy(self.keypoints).to(depth.device)
+        return ops.track_keypoints(self._kp_dev, depth, flow, self.K, self.K_inv, self.k, self.min_points,
+                                   first_index)
+
+    @staticmethod
+    def as_track_lists(tracks: np.ndarray, alive: np.ndarray, reseeded: np.ndarray, iteration: int):
+        """The driver's ``tracks_2D`` / ``track_start_z`` lists as they stand after
+        ``iteration`` (test_keypoints_flow.py:226-228,298-310): one list of (x, y, z) per
+        surviving track, oldest point first."""
+        start = max(i for i in range(iteration + 1) if reseeded[i])
+        out, start_z = [], []
+        for j in np.nonzero(alive[iteration])[0]:
+            out.append([tuple(tracks[i, j]) for i in range(start, iteration + 1)])
+            start_z.append(float(tracks[start, j, 2]))
+        return out, start_z
 
 
 # ---------------------------------------------------------------------------- pose

@@ -377,6 +377,45 @@ def pair_correspondences(kp, depth1, depth2, flow, K_inv, min_depth=0.0, max_dep
     return p1, p2, wgt, n_in
 
 
+def keypoints_to_2d(points: torch.Tensor, K):
+    """(..., 3) float64 camera-space points -> (uv (..., 2) float64, keep (...) bool); keep is
+    False where Z <= 0 (rows the reference's to_2d drops)."""
+    if points.shape[-1] != 3:
+        raise ValueError("points must be (..., 3)")
+    n = points.numel() // 3
+    uv = torch.empty(points.shape[:-1] + (2,), device=points.device, dtype=torch.float64)
+    keep = torch.empty(points.shape[:-1], device=points.device, dtype=torch.uint8)
+    _call("vo_keypoints_to_2d", _dev(points, "points", torch.float64), _host9(K), uv.data_ptr(), keep.data_ptr(),
+          n, _stream())
+    return uv, keep.bool()
+
+
+def track_keypoints(grid_kp: torch.Tensor, depth: torch.Tensor, flow: torch.Tensor, K, K_inv, k: int = 25,
+                    min_points: int = 4, first_index: int = 0):
+    """Multi-frame keypoint tracks over depth (F,H,W) and flow (F-1,2,H,W) ->
+    tracks (F-1,N,3) float64 (x, y, Z), alive (F-1,N) bool, reseeded (F-1) bool."""
+    if depth.dim() != 3:
+        raise ValueError("depth must be (F,H,W)")
+    F, H, W = depth.shape
+    if F < 1 or tuple(flow.shape) != (F - 1, 2, H, W):
+        raise ValueError("flow must be (F-1,2,H,W) matching the depth maps")
+    if grid_kp.dim() != 2 or grid_kp.shape[1] != 2:
+        raise ValueError("grid keypoints must be (N,2)")
+    if k < 1 or first_index < 0 or min_points < 0:
+        raise ValueError("k >= 1, first_index >= 0 and min_points >= 0 required")
+    N = grid_kp.shape[0]
+    dev = depth.device
+    tracks = torch.empty((F - 1, N, 3), device=dev, dtype=torch.float64)
+    alive = torch.empty((F - 1, N), device=dev, dtype=torch.uint8)
+    reseeded = torch.empty((F - 1,), device=dev, dtype=torch.uint8)
+    if F > 1:
+        _call("vo_track_keypoints", _dev(grid_kp, "keypoints", torch.float64) if N else 0,
+              _dev(depth, "depth", torch.float32), _dev(flow, "flow", torch.float32), _host9(K), _host9(K_inv),
+              int(first_index), int(k), int(min_points), tracks.data_ptr(), alive.data_ptr(), reseeded.data_ptr(),
+              F, N, H, W, _stream())
+    return tracks, alive.bool(), reseeded.bool()
+
+
 def kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None, offset=None):
     """(B,N,3) float64 point sets -> T (B,4,4) float64, n_used (B) int32."""
     if P.dim() != 3 or P.shape[2] != 3 or Q.shape != P.shape:

@@ -27,7 +27,7 @@ import torch
 
 from . import ops
 from .geometry import (HipCameraRansacXform, HipCameraSvdXform, HipKeypoints3DFlow, HipKeypoints3DXform,
-                       HipStereoDepth, UniformKeyPoints)
+                       HipKeypointTracker, HipStereoDepth, UniformKeyPoints)
 from .raft.models import RAFTStereoConfig
 from .raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT
 
@@ -77,6 +77,7 @@ class VisualOdometry:
         else:
             raise ValueError("VOConfig.pose must be 'svd' or 'ransac'")
         self.keypoints = self.pts_src.get_keypoints_device(cfg.max_keypoints)
+        self._cam = cam
 
     # -- stages ------------------------------------------------------------
     def depth_maps(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
@@ -128,7 +129,30 @@ class VisualOdometry:
         return torch.cat(Ts), torch.cat(sk)
 
 
+    @torch.no_grad()
+    def track_keypoints(self, left: torch.Tensor, right: torch.Tensor, k: int = 25, max_keypoints: int = 200,
+                        first_index: int = 0):
+        """The multi-frame keypoint tracks of test_keypoints_flow.py:235-310 for F
+        consecutive frames: depth for every frame, flow for every consecutive pair, then
+        all k-frame segments in one launch -> (tracks (F-1,N,3) f64, alive (F-1,N) bool,
+        reseeded (F-1) bool) on the GPU.  ``first_index`` is frame 0's index in the whole
+        sequence (seedings fall on multiples of ``k`` of the GLOBAL index)."""
+        grid = self.pts_src.get_keypoints(None, max_keypoints)
+        tracker = HipKeypointTracker(self._cam, grid, k=k, min_points=self.cfg.min_points)
+        return tracker.track_batch(self.depth_maps(left, right), self.flows(left), first_index)
+
+
 # ------------------------------------------------------------------ sharding
+
+def shard_segments(n_iterations: int, k: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [start, end) of tracking iterations for ``rank`` with ``start`` a
+    multiple of ``k``: keypoint tracks restart at every multiple of k, so blocks cut there
+    are independent.  Rank r needs frames start..end inclusive."""
+    segments = -(-n_iterations // k)
+    per = -(-segments // world)
+    start = min(rank * per * k, n_iterations)
+    return start, min(start + per * k, n_iterations)
+
 
 def shard_pairs(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block [start, end) of pair indices for ``rank``; blocks have
