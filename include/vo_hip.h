@@ -56,10 +56,13 @@ int vo_prepare_images(const uint8_t* gray, float* out, int frames, int H, int W,
  *   vo_instance_norm_relu   InstanceNorm2d (no affine, biased variance, eps) [+ ReLU]
  *   vo_channel_affine_relu  x*scale[c] + shift[c] [+ ReLU]  (BatchNorm2d inference)
  *   vo_add_relu             a = max(a + b, 0)                (residual join)
+ * skip (same shape as x, or NULL) folds the residual join into the same pass:
+ * x = max(skip + act(norm(x)), 0).
  * ------------------------------------------------------------------------- */
-int vo_instance_norm_relu(float* x, int64_t planes, int64_t hw, float eps, int relu, void* stream);
-int vo_channel_affine_relu(float* x, const float* scale, const float* shift, int64_t batch,
-                           int C, int64_t hw, int relu, void* stream);
+int vo_instance_norm_relu(float* x, const float* skip, int64_t planes, int64_t hw, float eps, int relu,
+                          void* stream);
+int vo_channel_affine_relu(float* x, const float* scale, const float* shift, const float* skip,
+                           int64_t batch, int C, int64_t hw, int relu, void* stream);
 int vo_add_relu(float* a, const float* b, int64_t n, void* stream);
 /* (planes,h,w) -> (planes,H,W) bilinear, corner-aligned (align_corners=True): the
  * inter-level state exchange of RAFT-Stereo's multi-level GRU. */

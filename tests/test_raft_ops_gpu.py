@@ -319,6 +319,16 @@ def test_fused_encoder_passes_match_stock_operators(vo):
         assert (got - want).abs().max().item() < 2e-5
         y = _rand(*shape, seed=22).to(DEV)
         assert torch.equal(ops.add_relu_(x.clone(), y), torch.relu(x + y))
+        # the residual join folded into the norm pass
+        want = torch.relu(y + torch.relu(nn.functional.instance_norm(x, eps=1e-5)))
+        assert (ops.instance_norm_relu_(x.clone(), 1e-5, True, skip=y) - want).abs().max().item() < 2e-5
+        with torch.no_grad():
+            want = torch.relu(y + torch.relu(bn(x)))
+            got = ops.channel_affine_relu_(x.clone(), scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous(),
+                                           True, skip=y)
+        assert (got - want).abs().max().item() < 2e-5
+        with pytest.raises(ValueError):
+            ops.instance_norm_relu_(x.clone(), 1e-5, True, skip=y[:, :, :-1] if shape[2] > 1 else y[:, :-1])
     # a whole encoder, fused against stock, both norm kinds
     for kind in ("instance", "batch"):
         torch.manual_seed(3)

@@ -5,7 +5,8 @@
 // stem works at full resolution).  As separate framework kernels that is 5-7 HBM
 // passes per convolution output (statistics, transform, clamp, add, clamp); fused
 // here it is 3 for instance norm (one read for the statistics, one read+write to
-// apply) and 2 for everything else.  All kernels work IN PLACE on the convolution
+// apply) and 2 for everything else; the residual join relu(skip + y) rides along in
+// the same pass for one more read.  All kernels work IN PLACE on the convolution
 // output, planes are (n, c) slices of an NCHW tensor, 16 bytes per lane.
 #include "vo_common.h"
 
@@ -24,10 +25,14 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 }
 
 // InstanceNorm2d (no affine, biased variance) + optional ReLU; one workgroup per plane.
-__global__ __launch_bounds__(256) void instnorm_kernel(float* __restrict__ x, int64_t hw, float eps, int relu) {
+// With ``skip`` the residual join is folded in: x = relu(skip + act(norm(x))).
+__global__ __launch_bounds__(256) void instnorm_kernel(float* __restrict__ x, const float* __restrict__ skip, int64_t hw,
+                                                       float eps, int relu) {
     __shared__ double scratch[4];
     float* p = x + (int64_t)blockIdx.x * hw;
-    const int64_t n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (hw >> 2) : 0;
+    const float* q = skip ? skip + (int64_t)blockIdx.x * hw : nullptr;
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+    const int64_t n4 = al ? (hw >> 2) : 0;
     float s = 0.0f, ss = 0.0f;
     double ds = 0.0, dss = 0.0;
     int since = 0;
@@ -49,33 +54,48 @@ __global__ __launch_bounds__(256) void instnorm_kernel(float* __restrict__ x, in
         float4 v = reinterpret_cast<float4*>(p)[i];
         v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
         if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        if (q) {
+            const float4 s4 = reinterpret_cast<const float4*>(q)[i];
+            v.x = fmaxf(v.x + s4.x, 0.0f); v.y = fmaxf(v.y + s4.y, 0.0f); v.z = fmaxf(v.z + s4.z, 0.0f); v.w = fmaxf(v.w + s4.w, 0.0f);
+        }
         reinterpret_cast<float4*>(p)[i] = v;
     }
     for (int64_t i = (n4 << 2) + threadIdx.x; i < hw; i += blockDim.x) {
         float v = (p[i] - m) * r;
-        p[i] = relu ? fmaxf(v, 0.0f) : v;
+        if (relu) v = fmaxf(v, 0.0f);
+        if (q) v = fmaxf(v + q[i], 0.0f);
+        p[i] = v;
     }
 }
 
 // y = x * scale[c] + shift[c] (+ ReLU): BatchNorm2d in inference with the running
 // statistics folded into scale / shift.  grid.y = plane, grid.x strides the plane.
 __global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ x, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, int C, int64_t hw, int relu) {
+                                                     const float* __restrict__ shift, const float* __restrict__ skip,
+                                                     int C, int64_t hw, int relu) {
     const int64_t plane = blockIdx.y;
     const float a = scale[plane % C], b = shift[plane % C];
     float* p = x + plane * hw;
-    const int64_t n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (hw >> 2) : 0;
+    const float* q = skip ? skip + plane * hw : nullptr;
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+    const int64_t n4 = al ? (hw >> 2) : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t; i < n4; i += stride) {
         float4 v = reinterpret_cast<float4*>(p)[i];
         v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
         if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        if (q) {
+            const float4 s4 = reinterpret_cast<const float4*>(q)[i];
+            v.x = fmaxf(v.x + s4.x, 0.0f); v.y = fmaxf(v.y + s4.y, 0.0f); v.z = fmaxf(v.z + s4.z, 0.0f); v.w = fmaxf(v.w + s4.w, 0.0f);
+        }
         reinterpret_cast<float4*>(p)[i] = v;
     }
     for (int64_t i = (n4 << 2) + t; i < hw; i += stride) {
-        const float v = p[i] * a + b;
-        p[i] = relu ? fmaxf(v, 0.0f) : v;
+        float v = p[i] * a + b;
+        if (relu) v = fmaxf(v, 0.0f);
+        if (q) v = fmaxf(v + q[i], 0.0f);
+        p[i] = v;
     }
 }
 
@@ -138,24 +158,25 @@ extern "C" int vo_resize_bilinear(const float* in, float* out, int64_t planes, i
     return VO_OK;
 }
 
-extern "C" int vo_instance_norm_relu(float* x, int64_t planes, int64_t hw, float eps, int relu, void* stream) {
+extern "C" int vo_instance_norm_relu(float* x, const float* skip, int64_t planes, int64_t hw, float eps, int relu,
+                                     void* stream) {
     VO_REQUIRE(x, "vo_instance_norm_relu: null pointer");
     VO_REQUIRE(planes > 0 && hw > 0, "vo_instance_norm_relu: bad sizes planes=%lld hw=%lld", (long long)planes, (long long)hw);
     if (planes > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_instance_norm_relu: too many planes");
-    instnorm_kernel<<<dim3((unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, hw, eps, relu);
+    instnorm_kernel<<<dim3((unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, skip, hw, eps, relu);
     VO_CHECK_LAUNCH("vo_instance_norm_relu");
     return VO_OK;
 }
 
-extern "C" int vo_channel_affine_relu(float* x, const float* scale, const float* shift, int64_t batch, int C,
-                                      int64_t hw, int relu, void* stream) {
+extern "C" int vo_channel_affine_relu(float* x, const float* scale, const float* shift, const float* skip,
+                                      int64_t batch, int C, int64_t hw, int relu, void* stream) {
     VO_REQUIRE(x && scale && shift, "vo_channel_affine_relu: null pointer");
     VO_REQUIRE(batch > 0 && C > 0 && hw > 0, "vo_channel_affine_relu: bad sizes");
     const int64_t planes = batch * C;
     if (planes > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_channel_affine_relu: batch*C=%lld exceeds 65535", (long long)planes);
     int64_t bx = vo_ceil_div(vo_ceil_div(hw, 4), 256);
     if (bx > 64) bx = 64;
-    affine_kernel<<<dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, scale, shift, C, hw, relu);
+    affine_kernel<<<dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, scale, shift, skip, C, hw, relu);
     VO_CHECK_LAUNCH("vo_channel_affine_relu");
     return VO_OK;
 }

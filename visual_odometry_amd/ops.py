@@ -73,21 +73,33 @@ def _host9(Kinv) -> "ctypes.Array":
 
 # ------------------------------------------------------- fused encoder passes
 
-def instance_norm_relu_(x: torch.Tensor, eps: float = 1e-5, relu: bool = True) -> torch.Tensor:
-    """In-place InstanceNorm2d (no affine) [+ ReLU] on an NCHW float32 tensor."""
+def _skip_ptr(skip, x):
+    if skip is None:
+        return 0
+    if skip.shape != x.shape:
+        raise ValueError("skip must have the shape of x")
+    return _dev(skip, "skip", torch.float32)
+
+
+def instance_norm_relu_(x: torch.Tensor, eps: float = 1e-5, relu: bool = True, skip: torch.Tensor | None = None) -> torch.Tensor:
+    """In-place InstanceNorm2d (no affine) [+ ReLU] on an NCHW float32 tensor; with ``skip``
+    the residual join follows in the same pass: x = relu(skip + act(norm(x)))."""
     N, C, H, W = x.shape
-    _call("vo_instance_norm_relu", _dev(x, "x", torch.float32), N * C, H * W, float(eps), int(relu), _stream(),
-          nbytes=3 * 4 * x.numel())              # statistics read + apply read/write
+    _call("vo_instance_norm_relu", _dev(x, "x", torch.float32), _skip_ptr(skip, x), N * C, H * W, float(eps), int(relu),
+          _stream(), nbytes=(3 + (skip is not None)) * 4 * x.numel())     # statistics read + apply read(s)/write
     return x
 
 
-def channel_affine_relu_(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool = True) -> torch.Tensor:
-    """In-place x*scale[c] + shift[c] [+ ReLU] on an NCHW float32 tensor."""
+def channel_affine_relu_(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool = True,
+                         skip: torch.Tensor | None = None) -> torch.Tensor:
+    """In-place x*scale[c] + shift[c] [+ ReLU] on an NCHW float32 tensor; with ``skip``
+    followed by x = relu(skip + x) in the same pass."""
     N, C, H, W = x.shape
     if scale.numel() != C or shift.numel() != C:
         raise ValueError("scale/shift must have one entry per channel")
     _call("vo_channel_affine_relu", _dev(x, "x", torch.float32), _dev(scale, "scale", torch.float32),
-          _dev(shift, "shift", torch.float32), N, C, H * W, int(relu), _stream(), nbytes=2 * 4 * x.numel())
+          _dev(shift, "shift", torch.float32), _skip_ptr(skip, x), N, C, H * W, int(relu), _stream(),
+          nbytes=(2 + (skip is not None)) * 4 * x.numel())
     return x
 
 

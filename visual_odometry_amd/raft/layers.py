@@ -42,21 +42,24 @@ def _fusable(x: torch.Tensor) -> bool:
     return fused_on() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
 
 
-def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool) -> torch.Tensor:
-    """relu(norm(conv(x))) (or without the ReLU).  Fused path: the convolution runs
-    WITHOUT its bias and one in-place HIP pass applies bias + norm + ReLU -- instance
-    norm removes any per-channel constant, so the bias drops out entirely; inference
-    batch norm absorbs it into its shift.  Stock operators otherwise."""
-    if _fusable(x):
+def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
+                  skip: torch.Tensor | None = None) -> torch.Tensor:
+    """relu(norm(conv(x))) (or without the ReLU); with ``skip`` the residual join
+    relu(skip + .) on top of it.  Fused path: the convolution runs WITHOUT its bias and
+    one in-place HIP pass applies bias + norm + ReLU (+ join) -- instance norm removes
+    any per-channel constant, so the bias drops out entirely; inference batch norm
+    absorbs it into its shift.  Stock operators otherwise."""
+    if _fusable(x) and (skip is None or (skip.is_cuda and skip.dtype == torch.float32 and skip.is_contiguous())):
         if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
             y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-            return ops.instance_norm_relu_(y, norm.eps, relu)
+            return ops.instance_norm_relu_(y, norm.eps, relu, skip)
         if isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats:
             y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             scale, shift = _folded_batch_norm(norm, conv.bias)
-            return ops.channel_affine_relu_(y, scale, shift, relu)
+            return ops.channel_affine_relu_(y, scale, shift, relu, skip)
     y = norm(conv(x))
-    return torch.relu_(y) if relu else y
+    y = torch.relu_(y) if relu else y
+    return y if skip is None else add_act(skip, y)
 
 
 def conv_act(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
@@ -126,10 +129,9 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         y = conv_norm_act(x, self.conv1, self.norm1, True)
-        y = conv_norm_act(y, self.conv2, self.norm2, True)
         if self.downsample is not None:
             x = conv_norm_act(x, self.downsample[0], self.norm3, False)
-        return add_act(x, y)
+        return conv_norm_act(y, self.conv2, self.norm2, True, skip=x)        # relu(x + relu(norm2(conv2(y))))
 
 
 def _init_weights(module: nn.Module):
