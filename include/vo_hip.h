@@ -48,45 +48,53 @@ int vo_prepare_images(const uint8_t* gray, float* out, int frames, int H, int W,
                       int pad_left, int pad_right, int pad_top, int pad_bottom,
                       int normalize, void* stream);
 
+/* Storage type of the conv nets' activation tensors in the fused passes below.  The
+ * reference runs both networks in float32 (mixed_precision=False, flow/flow_map_RAFT.py:38,
+ * stereo/stereo_disparity_RAFT.py:43); VO_F16 serves the published models'
+ * mixed_precision switch (stereo/raft_args.json:7).  Arithmetic is float32 either way;
+ * biases, scales and shifts are always float32. */
+enum { VO_F32 = 0, VO_F16 = 1 };
+
 /* ---------------------------------------------------------------------------
  * Fused, in-place normalisation / activation passes of the conv encoders (the
  * encoders themselves are part of the RAFT / RAFT-Stereo models the reference
  * instantiates at flow/flow_map_RAFT.py:42 and stereo/stereo_disparity_RAFT.py:46).
- * x: NCHW float32, planes = N*C slices of hw = H*W elements.
+ * x: NCHW of `dtype`, planes = N*C slices of hw = H*W elements.
  *   vo_instance_norm_relu   InstanceNorm2d (no affine, biased variance, eps) [+ ReLU]
  *   vo_channel_affine_relu  x*scale[c] + shift[c] [+ ReLU]  (BatchNorm2d inference)
  *   vo_add_relu             a = max(a + b, 0)                (residual join)
- * skip (same shape as x, or NULL) folds the residual join into the same pass:
- * x = max(skip + act(norm(x)), 0).
+ * skip (same shape and dtype as x, or NULL) folds the residual join into the same
+ * pass: x = max(skip + act(norm(x)), 0).
  * ------------------------------------------------------------------------- */
-int vo_instance_norm_relu(float* x, const float* skip, int64_t planes, int64_t hw, float eps, int relu,
-                          void* stream);
-int vo_channel_affine_relu(float* x, const float* scale, const float* shift, const float* skip,
-                           int64_t batch, int C, int64_t hw, int relu, void* stream);
-int vo_add_relu(float* a, const float* b, int64_t n, void* stream);
+int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, int64_t hw, float eps, int relu,
+                          int dtype, void* stream);
+int vo_channel_affine_relu(void* x, const float* scale, const float* shift, const void* skip,
+                           int64_t batch, int C, int64_t hw, int relu, int dtype, void* stream);
+int vo_add_relu(void* a, const void* b, int64_t n, int dtype, void* stream);
 /* (planes,h,w) -> (planes,H,W) bilinear, corner-aligned (align_corners=True): the
  * inter-level state exchange of RAFT-Stereo's multi-level GRU. */
-int vo_resize_bilinear(const float* in, float* out, int64_t planes, int h, int w, int H, int W, void* stream);
+int vo_resize_bilinear(const void* in, void* out, int64_t planes, int h, int w, int H, int W, int dtype,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------
  * Gate arithmetic of the convolutional GRUs (SepConvGRU of RAFT, ConvGRU of
  * RAFT-Stereo; same models, same call sites as above).  The z|r and q convolutions
  * run without bias in the framework; these passes add bias + context term, apply the
- * non-linearities and blend.  Contiguous operands are (B,C,hw) / (B,2C,hw) float32;
+ * non-linearities and blend.  Contiguous operands are (B,C,hw) / (B,2C,hw) of `dtype`;
  * a "batch stride" operand is a channel slice of a larger NCHW tensor (plane-
  * contiguous, consecutive batch items that many ELEMENTS apart).  cz/cr/cq, the
- * biases and h_copy may be NULL.
+ * biases (float32) and h_copy may be NULL.
  *   gates : z_out = sigmoid(zr[:, :C] + bz + cz);  rh_out = sigmoid(zr[:, C:] + br + cr) * h
  *   update: h_out = (1 - z)*h + z*tanh(q_conv + bq + cq)   (h_copy receives the same values)
  * ------------------------------------------------------------------------- */
-int vo_gru_gates(const float* zr_conv, const float* bias_z, const float* bias_r,
-                 const float* cz, int64_t cz_batch_stride, const float* cr, int64_t cr_batch_stride,
-                 const float* h, int64_t h_batch_stride, float* z_out,
-                 float* rh_out, int64_t rh_batch_stride, int batch, int C, int64_t hw, void* stream);
-int vo_gru_update(const float* q_conv, const float* bias_q, const float* cq, int64_t cq_batch_stride,
-                  const float* z, const float* h, int64_t h_batch_stride,
-                  float* h_out, int64_t out_batch_stride, float* h_copy, int64_t copy_batch_stride,
-                  int batch, int C, int64_t hw, void* stream);
+int vo_gru_gates(const void* zr_conv, const float* bias_z, const float* bias_r,
+                 const void* cz, int64_t cz_batch_stride, const void* cr, int64_t cr_batch_stride,
+                 const void* h, int64_t h_batch_stride, void* z_out,
+                 void* rh_out, int64_t rh_batch_stride, int batch, int C, int64_t hw, int dtype, void* stream);
+int vo_gru_update(const void* q_conv, const float* bias_q, const void* cq, int64_t cq_batch_stride,
+                  const void* z, const void* h, int64_t h_batch_stride,
+                  void* h_out, int64_t out_batch_stride, void* h_copy, int64_t copy_batch_stride,
+                  int batch, int C, int64_t hw, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * All-pairs correlation volume (RAFT CorrBlock / RAFT-Stereo CorrBlock1D "reg").

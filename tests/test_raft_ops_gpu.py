@@ -382,3 +382,54 @@ def test_resize_bilinear_matches_interpolate(vo, shape, size):
     # the source coordinate scale*x may differ by one float ulp (fused vs separate multiply):
     # up to ~8e-6 of a pixel at these widths, times the local slope of the data
     assert got.shape == want.shape and (got - want).abs().max().item() < 1e-4
+
+
+def test_fused_passes_in_float16_storage(vo):
+    """The float16-storage variants of the fused passes against float32 math on the same
+    (already rounded) inputs: only the final rounding to float16 may differ."""
+    import torch.nn as nn
+    from visual_odometry_amd import ops
+    for shape in [(2, 6, 37, 40), (1, 64, 60, 80), (2, 3, 5, 7)]:
+        x = (_rand(*shape, seed=41, scale=2.0) + 0.5).half().to(DEV)
+        y = _rand(*shape, seed=42).half().to(DEV)
+        xf, yf = x.float(), y.float()
+        want = torch.relu(yf + torch.relu(nn.functional.instance_norm(xf, eps=1e-5)))
+        got = ops.instance_norm_relu_(x.clone(), 1e-5, True, skip=y)
+        assert got.dtype == torch.float16 and (got.float() - want).abs().max().item() < 4e-3
+        scale, shift = _rand(shape[1], seed=43).to(DEV), _rand(shape[1], seed=44).to(DEV)
+        want = torch.relu(xf * scale[None, :, None, None] + shift[None, :, None, None])
+        got = ops.channel_affine_relu_(x.clone(), scale, shift, True)
+        assert (got.float() - want).abs().max().item() < 1e-2 * max(1.0, want.abs().max().item()) * 0.1
+        assert torch.equal(ops.add_relu_(x.clone(), y), torch.relu(xf + yf).half())
+        up = ops.resize_bilinear(x, (shape[2] * 2, shape[3] * 2))
+        want = nn.functional.interpolate(xf, (shape[2] * 2, shape[3] * 2), mode="bilinear", align_corners=True)
+        assert up.dtype == torch.float16 and (up.float() - want).abs().max().item() < 4e-3
+    with pytest.raises(ValueError):
+        ops.add_relu_(x.clone(), y.float())
+    with pytest.raises(ValueError):
+        ops.instance_norm_relu_(x.double())
+
+
+def test_mixed_precision_stays_within_the_flow_budget(vo):
+    """float16 activations in both networks: flow and disparity stay within the 0.05 px
+    mean end-point-error budget of the float32 path (the reference's precision)."""
+    from visual_odometry_amd import synthetic as syn
+    from visual_odometry_amd.pipeline import VisualOdometry, VOConfig
+    from visual_odometry_amd.raft.models import RAFTStereoConfig
+    H, W, F = 128, 160, 4
+    left, right = syn.stereo_sequence(5, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    outs = []
+    for stereo_cfg in (RAFTStereoConfig.realtime(), RAFTStereoConfig()):
+        res = []
+        for mixed in (False, True):
+            pipe = VisualOdometry(VOConfig(iters=6, stereo=stereo_cfg, mixed_precision=mixed), syn.left_K(0.25),
+                                  syn.focal_length_px() * 0.25, syn.baseline(), np.ones((H, W), bool), seed=0)
+            with torch.no_grad():
+                res.append((pipe.flows(l), pipe.disparity_solver.compute_disparity_gray_batch(l, r)))
+        (f32, d32), (f16, d16) = res
+        assert f16.dtype == torch.float32 and d16.dtype == torch.float32
+        epe = (f16 - f32).pow(2).sum(1).sqrt().mean().item()
+        derr = (d16 - d32).abs().mean().item()
+        assert epe < 0.05 and derr < 0.05, (epe, derr)
+        assert epe > 0 and derr > 0            # the switch did change the arithmetic

@@ -18,12 +18,12 @@ _P, _I, _L, _D, _F = c_void_p, c_int, c_int64, c_double, c_float
 
 # name -> argtypes; every function returns int except the two below.
 SIGNATURES = {
-    "vo_instance_norm_relu": [_P, _P, _L, _L, _F, _I, _P],
-    "vo_channel_affine_relu": [_P, _P, _P, _P, _L, _I, _L, _I, _P],
-    "vo_add_relu": [_P, _P, _L, _P],
-    "vo_resize_bilinear": [_P, _P, _L, _I, _I, _I, _I, _P],
-    "vo_gru_gates": [_P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _L, _P],
-    "vo_gru_update": [_P, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _I, _L, _P],
+    "vo_instance_norm_relu": [_P, _P, _L, _L, _F, _I, _I, _P],
+    "vo_channel_affine_relu": [_P, _P, _P, _P, _L, _I, _L, _I, _I, _P],
+    "vo_add_relu": [_P, _P, _L, _I, _P],
+    "vo_resize_bilinear": [_P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "vo_gru_gates": [_P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _L, _I, _P],
+    "vo_gru_update": [_P, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _I, _L, _I, _P],
     "vo_prepare_images": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_corr_volume_2d": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_1d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -7,7 +7,8 @@
 // here it is 3 for instance norm (one read for the statistics, one read+write to
 // apply) and 2 for everything else; the residual join relu(skip + y) rides along in
 // the same pass for one more read.  All kernels work IN PLACE on the convolution
-// output, planes are (n, c) slices of an NCHW tensor, 16 bytes per lane.
+// output, planes are (n, c) slices of an NCHW tensor stored as float32 or float16,
+// four elements per lane and access, arithmetic in float32.
 #include "vo_common.h"
 
 namespace {
@@ -24,25 +25,34 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     return t;
 }
 
+__device__ __forceinline__ float4 relu4(float4 v) {
+    return make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <typename T> __device__ __forceinline__ bool aligned4(const T* a, const T* b) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & (4 * sizeof(T) - 1)) == 0;
+}
+
 // InstanceNorm2d (no affine, biased variance) + optional ReLU; one workgroup per plane.
 // With ``skip`` the residual join is folded in: x = relu(skip + act(norm(x))).
-__global__ __launch_bounds__(256) void instnorm_kernel(float* __restrict__ x, const float* __restrict__ skip, int64_t hw,
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_kernel(T* __restrict__ x, const T* __restrict__ skip, int64_t hw,
                                                        float eps, int relu) {
     __shared__ double scratch[4];
-    float* p = x + (int64_t)blockIdx.x * hw;
-    const float* q = skip ? skip + (int64_t)blockIdx.x * hw : nullptr;
-    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
-    const int64_t n4 = al ? (hw >> 2) : 0;
+    T* p = x + (int64_t)blockIdx.x * hw;
+    const T* q = skip ? skip + (int64_t)blockIdx.x * hw : nullptr;
+    const int64_t n4 = aligned4<T>(p, q) ? (hw >> 2) : 0;
     float s = 0.0f, ss = 0.0f;
     double ds = 0.0, dss = 0.0;
     int since = 0;
     for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        const float4 v = vo_ld4<T>(p, i);
         s += (v.x + v.y) + (v.z + v.w);
         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         if (++since == 64) { ds += s; dss += ss; s = 0.0f; ss = 0.0f; since = 0; }   // bound the float32 run length
     }
-    for (int64_t i = (n4 << 2) + threadIdx.x; i < hw; i += blockDim.x) { const float v = p[i]; s += v; ss += v * v; }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < hw; i += blockDim.x) { const float v = vo_ld1(p, i); s += v; ss += v * v; }
     ds += s; dss += ss;
     const double tot = block_sum(ds, scratch);
     const double tot2 = block_sum(dss, scratch);
@@ -51,73 +61,64 @@ __global__ __launch_bounds__(256) void instnorm_kernel(float* __restrict__ x, co
     if (var < 0.0) var = 0.0;
     const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
     for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
-        float4 v = reinterpret_cast<float4*>(p)[i];
+        float4 v = vo_ld4<T>(p, i);
         v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
-        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
-        if (q) {
-            const float4 s4 = reinterpret_cast<const float4*>(q)[i];
-            v.x = fmaxf(v.x + s4.x, 0.0f); v.y = fmaxf(v.y + s4.y, 0.0f); v.z = fmaxf(v.z + s4.z, 0.0f); v.w = fmaxf(v.w + s4.w, 0.0f);
-        }
-        reinterpret_cast<float4*>(p)[i] = v;
+        if (relu) v = relu4(v);
+        if (q) v = relu4(add4(v, vo_ld4<T>(q, i)));
+        vo_st4<T>(p, i, v);
     }
     for (int64_t i = (n4 << 2) + threadIdx.x; i < hw; i += blockDim.x) {
-        float v = (p[i] - m) * r;
+        float v = (vo_ld1(p, i) - m) * r;
         if (relu) v = fmaxf(v, 0.0f);
-        if (q) v = fmaxf(v + q[i], 0.0f);
-        p[i] = v;
+        if (q) v = fmaxf(v + vo_ld1(q, i), 0.0f);
+        vo_st1(p, i, v);
     }
 }
 
-// y = x * scale[c] + shift[c] (+ ReLU): BatchNorm2d in inference with the running
-// statistics folded into scale / shift.  grid.y = plane, grid.x strides the plane.
-__global__ __launch_bounds__(256) void affine_kernel(float* __restrict__ x, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, const float* __restrict__ skip,
+// y = x * scale[c] + shift[c] (+ ReLU) (+ residual join): BatchNorm2d in inference with
+// the running statistics folded into scale / shift, or a convolution's bias + ReLU.
+// grid.y = plane, grid.x strides the plane.
+template <typename T>
+__global__ __launch_bounds__(256) void affine_kernel(T* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const T* __restrict__ skip,
                                                      int C, int64_t hw, int relu) {
     const int64_t plane = blockIdx.y;
     const float a = scale[plane % C], b = shift[plane % C];
-    float* p = x + plane * hw;
-    const float* q = skip ? skip + plane * hw : nullptr;
-    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
-    const int64_t n4 = al ? (hw >> 2) : 0;
+    T* p = x + plane * hw;
+    const T* q = skip ? skip + plane * hw : nullptr;
+    const int64_t n4 = aligned4<T>(p, q) ? (hw >> 2) : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t i = t; i < n4; i += stride) {
-        float4 v = reinterpret_cast<float4*>(p)[i];
+        float4 v = vo_ld4<T>(p, i);
         v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
-        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
-        if (q) {
-            const float4 s4 = reinterpret_cast<const float4*>(q)[i];
-            v.x = fmaxf(v.x + s4.x, 0.0f); v.y = fmaxf(v.y + s4.y, 0.0f); v.z = fmaxf(v.z + s4.z, 0.0f); v.w = fmaxf(v.w + s4.w, 0.0f);
-        }
-        reinterpret_cast<float4*>(p)[i] = v;
+        if (relu) v = relu4(v);
+        if (q) v = relu4(add4(v, vo_ld4<T>(q, i)));
+        vo_st4<T>(p, i, v);
     }
     for (int64_t i = (n4 << 2) + t; i < hw; i += stride) {
-        float v = p[i] * a + b;
+        float v = vo_ld1(p, i) * a + b;
         if (relu) v = fmaxf(v, 0.0f);
-        if (q) v = fmaxf(v + q[i], 0.0f);
-        p[i] = v;
+        if (q) v = fmaxf(v + vo_ld1(q, i), 0.0f);
+        vo_st1(p, i, v);
     }
 }
 
 // a = relu(a + b)
-__global__ __launch_bounds__(256) void add_relu_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_relu_kernel(T* __restrict__ a, const T* __restrict__ b, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
-    const int64_t n4 = al ? (n >> 2) : 0;
-    for (int64_t i = t; i < n4; i += stride) {
-        float4 u = reinterpret_cast<float4*>(a)[i];
-        const float4 v = reinterpret_cast<const float4*>(b)[i];
-        u.x = fmaxf(u.x + v.x, 0.0f); u.y = fmaxf(u.y + v.y, 0.0f); u.z = fmaxf(u.z + v.z, 0.0f); u.w = fmaxf(u.w + v.w, 0.0f);
-        reinterpret_cast<float4*>(a)[i] = u;
-    }
-    for (int64_t i = (n4 << 2) + t; i < n; i += stride) a[i] = fmaxf(a[i] + b[i], 0.0f);
+    const int64_t n4 = aligned4<T>(a, b) ? (n >> 2) : 0;
+    for (int64_t i = t; i < n4; i += stride) vo_st4<T>(a, i, relu4(add4(vo_ld4<T>(a, i), vo_ld4<T>(b, i))));
+    for (int64_t i = (n4 << 2) + t; i < n; i += stride) vo_st1(a, i, fmaxf(vo_ld1(a, i) + vo_ld1(b, i), 0.0f));
 }
 
 // Bilinear resize with corner-aligned sampling (F.interpolate(mode="bilinear",
 // align_corners=True)): the inter-level exchange of RAFT-Stereo's multi-level GRU.
 // One lane per 4 output pixels of a row; source rows are re-read from L2.
-__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total,
+template <typename T>
+__global__ __launch_bounds__(256) void resize_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t total,
                                                      int h, int w, int H, int W, float sy, float sx) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
     const float fy = sy * (float)y;
     const int y0 = min((int)fy, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
     const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
-    const float* r0 = in + (plane * h + y0) * (int64_t)w;
-    const float* r1 = in + (plane * h + y1) * (int64_t)w;
-    float* o = out + (plane * H + y) * (int64_t)W + 4 * xq;
+    const T* r0 = in + (plane * h + y0) * (int64_t)w;
+    const T* r1 = in + (plane * h + y1) * (int64_t)w;
+    T* o = out + (plane * H + y) * (int64_t)W + 4 * xq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int x = 4 * xq + i;
@@ -138,55 +139,80 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ i
         const float fx = sx * (float)x;
         const int x0 = min((int)fx, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
         const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
-        o[i] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+        vo_st1(o, i, ly0 * (lx0 * vo_ld1(r0, x0) + lx1 * vo_ld1(r0, x1)) + ly1 * (lx0 * vo_ld1(r1, x0) + lx1 * vo_ld1(r1, x1)));
     }
+}
+
+int check_dtype(const char* fn, int dtype) {
+    if (dtype != VO_F32 && dtype != VO_F16) return vo_fail(VO_ERR_INVALID_ARG, "%s: dtype=%d is neither VO_F32 nor VO_F16", fn, dtype);
+    return VO_OK;
 }
 
 }  // namespace
 
-extern "C" int vo_resize_bilinear(const float* in, float* out, int64_t planes, int h, int w, int H, int W,
+extern "C" int vo_resize_bilinear(const void* in, void* out, int64_t planes, int h, int w, int H, int W, int dtype,
                                   void* stream) {
     VO_REQUIRE(in && out, "vo_resize_bilinear: null pointer");
     VO_REQUIRE(planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "vo_resize_bilinear: bad sizes");
+    if (int rc = check_dtype("vo_resize_bilinear", dtype)) return rc;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
     const int64_t total = planes * H * ((W + 3) / 4);
     const int64_t blocks = vo_ceil_div(total, 256);
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_resize_bilinear: grid too large");
-    resize_kernel<<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(in, out, total, h, w, H, W, sy, sx);
+    const dim3 grid((unsigned)blocks);
+    if (dtype == VO_F16)
+        resize_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((const __half*)in, (__half*)out, total, h, w, H, W, sy, sx);
+    else
+        resize_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((const float*)in, (float*)out, total, h, w, H, W, sy, sx);
     VO_CHECK_LAUNCH("vo_resize_bilinear");
     return VO_OK;
 }
 
-extern "C" int vo_instance_norm_relu(float* x, const float* skip, int64_t planes, int64_t hw, float eps, int relu,
-                                     void* stream) {
+extern "C" int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, int64_t hw, float eps, int relu,
+                                     int dtype, void* stream) {
     VO_REQUIRE(x, "vo_instance_norm_relu: null pointer");
     VO_REQUIRE(planes > 0 && hw > 0, "vo_instance_norm_relu: bad sizes planes=%lld hw=%lld", (long long)planes, (long long)hw);
+    if (int rc = check_dtype("vo_instance_norm_relu", dtype)) return rc;
     if (planes > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_instance_norm_relu: too many planes");
-    instnorm_kernel<<<dim3((unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, skip, hw, eps, relu);
+    const dim3 grid((unsigned)planes);
+    if (dtype == VO_F16)
+        instnorm_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, (const __half*)skip, hw, eps, relu);
+    else
+        instnorm_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, hw, eps, relu);
     VO_CHECK_LAUNCH("vo_instance_norm_relu");
     return VO_OK;
 }
 
-extern "C" int vo_channel_affine_relu(float* x, const float* scale, const float* shift, const float* skip,
-                                      int64_t batch, int C, int64_t hw, int relu, void* stream) {
+extern "C" int vo_channel_affine_relu(void* x, const float* scale, const float* shift, const void* skip,
+                                      int64_t batch, int C, int64_t hw, int relu, int dtype, void* stream) {
     VO_REQUIRE(x && scale && shift, "vo_channel_affine_relu: null pointer");
     VO_REQUIRE(batch > 0 && C > 0 && hw > 0, "vo_channel_affine_relu: bad sizes");
+    if (int rc = check_dtype("vo_channel_affine_relu", dtype)) return rc;
     const int64_t planes = batch * C;
     if (planes > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_channel_affine_relu: batch*C=%lld exceeds 65535", (long long)planes);
     int64_t bx = vo_ceil_div(vo_ceil_div(hw, 4), 256);
     if (bx > 64) bx = 64;
-    affine_kernel<<<dim3((unsigned)bx, (unsigned)planes), dim3(256), 0, vo_stream(stream)>>>(x, scale, shift, skip, C, hw, relu);
+    const dim3 grid((unsigned)bx, (unsigned)planes);
+    if (dtype == VO_F16)
+        affine_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, scale, shift, (const __half*)skip, C, hw, relu);
+    else
+        affine_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, scale, shift, (const float*)skip, C, hw, relu);
     VO_CHECK_LAUNCH("vo_channel_affine_relu");
     return VO_OK;
 }
 
-extern "C" int vo_add_relu(float* a, const float* b, int64_t n, void* stream) {
+extern "C" int vo_add_relu(void* a, const void* b, int64_t n, int dtype, void* stream) {
     VO_REQUIRE(a && b, "vo_add_relu: null pointer");
     VO_REQUIRE(n > 0, "vo_add_relu: n=%lld", (long long)n);
+    if (int rc = check_dtype("vo_add_relu", dtype)) return rc;
     int64_t blocks = vo_ceil_div(vo_ceil_div(n, 4), 256);
     if (blocks > 4096) blocks = 4096;
-    add_relu_kernel<<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(a, b, n);
+    const dim3 grid((unsigned)blocks);
+    if (dtype == VO_F16)
+        add_relu_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)a, (const __half*)b, n);
+    else
+        add_relu_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)a, (const float*)b, n);
     VO_CHECK_LAUNCH("vo_add_relu");
     return VO_OK;
 }

@@ -73,33 +73,51 @@ def _host9(Kinv) -> "ctypes.Array":
 
 # ------------------------------------------------------- fused encoder passes
 
+VO_F32, VO_F16 = 0, 1        # storage codes of the fused conv-net passes (include/vo_hip.h)
+
+
+def _act(t: torch.Tensor, name: str, like: torch.Tensor | None = None):
+    """Contiguous float32 / float16 GPU activation tensor -> (ptr, dtype code, bytes per element)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor (the HIP backend has no CPU path)")
+    if t.dtype not in (torch.float32, torch.float16):
+        raise ValueError(f"{name}: expected float32 or float16, got {t.dtype}")
+    if like is not None and t.dtype != like.dtype:
+        raise ValueError(f"{name}: dtype {t.dtype} differs from {like.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr(), (VO_F16 if t.dtype == torch.float16 else VO_F32), t.element_size()
+
+
 def _skip_ptr(skip, x):
     if skip is None:
         return 0
     if skip.shape != x.shape:
         raise ValueError("skip must have the shape of x")
-    return _dev(skip, "skip", torch.float32)
+    return _act(skip, "skip", x)[0]
 
 
 def instance_norm_relu_(x: torch.Tensor, eps: float = 1e-5, relu: bool = True, skip: torch.Tensor | None = None) -> torch.Tensor:
-    """In-place InstanceNorm2d (no affine) [+ ReLU] on an NCHW float32 tensor; with ``skip``
-    the residual join follows in the same pass: x = relu(skip + act(norm(x)))."""
+    """In-place InstanceNorm2d (no affine) [+ ReLU] on an NCHW float32/float16 tensor; with
+    ``skip`` the residual join follows in the same pass: x = relu(skip + act(norm(x)))."""
     N, C, H, W = x.shape
-    _call("vo_instance_norm_relu", _dev(x, "x", torch.float32), _skip_ptr(skip, x), N * C, H * W, float(eps), int(relu),
-          _stream(), nbytes=(3 + (skip is not None)) * 4 * x.numel())     # statistics read + apply read(s)/write
+    px, dt, es = _act(x, "x")
+    _call("vo_instance_norm_relu", px, _skip_ptr(skip, x), N * C, H * W, float(eps), int(relu), dt,
+          _stream(), nbytes=(3 + (skip is not None)) * es * x.numel())     # statistics read + apply read(s)/write
     return x
 
 
 def channel_affine_relu_(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool = True,
                          skip: torch.Tensor | None = None) -> torch.Tensor:
-    """In-place x*scale[c] + shift[c] [+ ReLU] on an NCHW float32 tensor; with ``skip``
-    followed by x = relu(skip + x) in the same pass."""
+    """In-place x*scale[c] + shift[c] [+ ReLU] on an NCHW float32/float16 tensor (scale and
+    shift float32); with ``skip`` followed by x = relu(skip + x) in the same pass."""
     N, C, H, W = x.shape
     if scale.numel() != C or shift.numel() != C:
         raise ValueError("scale/shift must have one entry per channel")
-    _call("vo_channel_affine_relu", _dev(x, "x", torch.float32), _dev(scale, "scale", torch.float32),
-          _dev(shift, "shift", torch.float32), _skip_ptr(skip, x), N, C, H * W, int(relu), _stream(),
-          nbytes=(2 + (skip is not None)) * 4 * x.numel())
+    px, dt, es = _act(x, "x")
+    _call("vo_channel_affine_relu", px, _dev(scale, "scale", torch.float32),
+          _dev(shift, "shift", torch.float32), _skip_ptr(skip, x), N, C, H * W, int(relu), dt, _stream(),
+          nbytes=(2 + (skip is not None)) * es * x.numel())
     return x
 
 
@@ -107,8 +125,8 @@ def add_relu_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """In-place a = relu(a + b)."""
     if a.shape != b.shape:
         raise ValueError("add_relu_: shapes differ")
-    _call("vo_add_relu", _dev(a, "a", torch.float32), _dev(b, "b", torch.float32), a.numel(), _stream(),
-          nbytes=3 * 4 * a.numel())
+    pa, dt, es = _act(a, "a")
+    _call("vo_add_relu", pa, _act(b, "b", a)[0], a.numel(), dt, _stream(), nbytes=3 * es * a.numel())
     return a
 
 
@@ -116,19 +134,22 @@ def resize_bilinear(x: torch.Tensor, size) -> torch.Tensor:
     """(B,C,h,w) -> (B,C,H,W), bilinear with align_corners=True."""
     B, C, h, w = x.shape
     H, W = int(size[0]), int(size[1])
-    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
-    _call("vo_resize_bilinear", _dev(x, "x", torch.float32), out.data_ptr(), B * C, h, w, H, W, _stream(),
-          nbytes=4 * (x.numel() + out.numel()))
+    px, dt, es = _act(x, "x")
+    out = torch.empty((B, C, H, W), device=x.device, dtype=x.dtype)
+    _call("vo_resize_bilinear", px, out.data_ptr(), B * C, h, w, H, W, dt, _stream(),
+          nbytes=es * (x.numel() + out.numel()))
     return out
 
 
-def _slice(t, name: str):
-    """A (B,C,H,W) float32 GPU tensor whose (C,H,W) block is dense but whose batch items
-    may be further apart (a channel slice of a bigger NCHW tensor) -> (ptr, batch stride)."""
+def _slice(t, name: str, like: torch.Tensor | None = None):
+    """A (B,C,H,W) GPU tensor whose (C,H,W) block is dense but whose batch items may be
+    further apart (a channel slice of a bigger NCHW tensor) -> (ptr, batch stride)."""
     if t is None:
         return 0, 0
-    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
-        raise ValueError(f"{name}: expected a 4-D float32 GPU tensor")
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dim() != 4 or t.dtype not in (torch.float32, torch.float16):
+        raise ValueError(f"{name}: expected a 4-D float32/float16 GPU tensor")
+    if like is not None and t.dtype != like.dtype:
+        raise ValueError(f"{name}: dtype {t.dtype} differs from {like.dtype}")
     B, C, H, W = t.shape
     st = t.stride()
     if not (st[3] == 1 and st[2] == W and st[1] == H * W):
@@ -142,11 +163,13 @@ def gru_gates(zr: torch.Tensor, bias_z, bias_r, cz, cr, h: torch.Tensor, rh_out:
     C = C2 // 2
     if tuple(h.shape) != (B, C, H, W) or tuple(rh_out.shape) != (B, C, H, W):
         raise ValueError("gru_gates: h / rh_out must be (B,C,H,W) with zr (B,2C,H,W)")
-    z = torch.empty((B, C, H, W), device=zr.device, dtype=torch.float32)
-    pcz, scz = _slice(cz, "cz"); pcr, scr = _slice(cr, "cr"); ph, sh = _slice(h, "h"); prh, srh = _slice(rh_out, "rh_out")
-    _call("vo_gru_gates", _dev(zr, "zr", torch.float32), _opt(bias_z, "bias_z", torch.float32),
-          _opt(bias_r, "bias_r", torch.float32), pcz, scz, pcr, scr, ph, sh, z.data_ptr(), prh, srh, B, C, H * W,
-          _stream(), nbytes=4 * z.numel() * (5 + (cz is not None) + (cr is not None)))
+    pzr, dt, es = _act(zr, "zr")
+    z = torch.empty((B, C, H, W), device=zr.device, dtype=zr.dtype)
+    pcz, scz = _slice(cz, "cz", zr); pcr, scr = _slice(cr, "cr", zr); ph, sh = _slice(h, "h", zr)
+    prh, srh = _slice(rh_out, "rh_out", zr)
+    _call("vo_gru_gates", pzr, _opt(bias_z, "bias_z", torch.float32),
+          _opt(bias_r, "bias_r", torch.float32), pcz, scz, pcr, scr, ph, sh, z.data_ptr(), prh, srh, B, C, H * W, dt,
+          _stream(), nbytes=es * z.numel() * (5 + (cz is not None) + (cr is not None)))
     return z
 
 
@@ -156,10 +179,12 @@ def gru_update(q: torch.Tensor, bias_q, cq, z: torch.Tensor, h: torch.Tensor, h_
     for t, n in ((z, "z"), (h, "h"), (h_out, "h_out")):
         if tuple(t.shape) != (B, C, H, W):
             raise ValueError(f"gru_update: {n} must be (B,C,H,W)")
-    pcq, scq = _slice(cq, "cq"); ph, sh = _slice(h, "h"); po, so = _slice(h_out, "h_out"); pc, sc = _slice(h_copy, "h_copy")
-    _call("vo_gru_update", _dev(q, "q", torch.float32), _opt(bias_q, "bias_q", torch.float32), pcq, scq,
-          _dev(z, "z", torch.float32), ph, sh, po, so, pc, sc, B, C, H * W, _stream(),
-          nbytes=4 * q.numel() * (4 + (cq is not None) + (h_copy is not None)))
+    pq, dt, es = _act(q, "q")
+    pcq, scq = _slice(cq, "cq", q); ph, sh = _slice(h, "h", q); po, so = _slice(h_out, "h_out", q)
+    pc, sc = _slice(h_copy, "h_copy", q)
+    _call("vo_gru_update", pq, _opt(bias_q, "bias_q", torch.float32), pcq, scq,
+          _act(z, "z", q)[0], ph, sh, po, so, pc, sc, B, C, H * W, dt, _stream(),
+          nbytes=es * q.numel() * (4 + (cq is not None) + (h_copy is not None)))
     return h_out
 
 

@@ -46,6 +46,7 @@ class VOConfig:
     ransac_threshold: float = 0.05        # camera_svd_xform.py:58
     ransac_iterations: int = 1000
     ransac_seed: int = 0
+    mixed_precision: bool = False         # the models' switch; the reference passes False (flow_map_RAFT.py:38)
 
 
 class _Rig:
@@ -61,8 +62,10 @@ class VisualOdometry:
     def __init__(self, cfg: VOConfig, K: np.ndarray, focal_length_px, baseline, mask: np.ndarray,
                  flow_checkpoint: Optional[str] = None, stereo_checkpoint: Optional[str] = None, seed: int = 0):
         self.cfg = cfg
-        self.flow_solver = HipOpticalFlowRAFT(flow_checkpoint, None, cfg.iters, seed=seed)
-        self.disparity_solver = HipDisparityRAFT(stereo_checkpoint, None, cfg.iters, config=cfg.stereo, seed=seed + 1)
+        self.flow_solver = HipOpticalFlowRAFT(flow_checkpoint, None, cfg.iters, seed=seed,
+                                              mixed_precision=cfg.mixed_precision)
+        self.disparity_solver = HipDisparityRAFT(stereo_checkpoint, None, cfg.iters, config=cfg.stereo, seed=seed + 1,
+                                                 mixed_precision=cfg.mixed_precision)
         self.device = self.flow_solver.device
         self._fxB = focal_length_px * baseline
         self._f64 = isinstance(self._fxB, np.float64)

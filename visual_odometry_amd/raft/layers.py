@@ -38,8 +38,38 @@ def fused_on() -> bool:
     return _FUSED and not torch.is_autocast_enabled()
 
 
+_ACT_DTYPES = (torch.float32, torch.float16)
+
+
 def _fusable(x: torch.Tensor) -> bool:
-    return fused_on() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    return fused_on() and x.is_cuda and x.dtype in _ACT_DTYPES and x.is_contiguous()
+
+
+def weight_for(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """The convolution's weight in the dtype of its input: the float32 parameter itself,
+    or a float16 copy cached on the module (rebuilt when the parameter changes or moves).
+    The mixed-precision path keeps float32 master weights and float16 activations."""
+    if x.dtype == conv.weight.dtype:
+        return conv.weight
+    key = (conv.weight._version, conv.weight.data_ptr(), x.dtype)
+    cached = getattr(conv, "_vo_weight_cast", None)
+    if cached is None or cached[0] != key:
+        cached = (key, conv.weight.detach().to(x.dtype).contiguous(),
+                  None if conv.bias is None else conv.bias.detach().to(x.dtype).contiguous())
+        conv._vo_weight_cast = cached
+    return cached[1]
+
+
+def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """conv(x) with bias, weights cast to the activations' dtype when they differ."""
+    if x.dtype == conv.weight.dtype:
+        return conv(x)
+    w = weight_for(conv, x)
+    return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    return F.conv2d(x, weight_for(conv, x), None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
@@ -49,14 +79,12 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
     one in-place HIP pass applies bias + norm + ReLU (+ join) -- instance norm removes
     any per-channel constant, so the bias drops out entirely; inference batch norm
     absorbs it into its shift.  Stock operators otherwise."""
-    if _fusable(x) and (skip is None or (skip.is_cuda and skip.dtype == torch.float32 and skip.is_contiguous())):
+    if _fusable(x) and (skip is None or (skip.is_cuda and skip.dtype == x.dtype and skip.is_contiguous())):
         if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
-            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-            return ops.instance_norm_relu_(y, norm.eps, relu, skip)
+            return ops.instance_norm_relu_(_conv_nobias(x, conv), norm.eps, relu, skip)
         if isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats:
-            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             scale, shift = _folded_batch_norm(norm, conv.bias)
-            return ops.channel_affine_relu_(y, scale, shift, relu, skip)
+            return ops.channel_affine_relu_(_conv_nobias(x, conv), scale, shift, relu, skip)
     y = norm(conv(x))
     y = torch.relu_(y) if relu else y
     return y if skip is None else add_act(skip, y)
@@ -65,13 +93,13 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
 def conv_act(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     """relu(conv(x)); fused: bias-free convolution, then bias + ReLU in one in-place pass."""
     if _fusable(x) and conv.bias is not None:
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = _conv_nobias(x, conv)
         ones = getattr(conv, "_vo_ones", None)
         if ones is None or ones.device != y.device:
             ones = torch.ones(conv.out_channels, device=y.device, dtype=torch.float32)
             conv._vo_ones = ones
         return ops.channel_affine_relu_(y, ones, conv.bias, True)
-    return torch.relu_(conv(x))
+    return torch.relu_(conv_plain(x, conv))
 
 
 def _folded_batch_norm(norm: nn.BatchNorm2d, conv_bias=None):
@@ -93,7 +121,7 @@ def _folded_batch_norm(norm: nn.BatchNorm2d, conv_bias=None):
 
 def add_act(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """relu(x + y); in place into y (a fresh conv output) when fused."""
-    if _fusable(y) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape == y.shape:
+    if _fusable(y) and x.is_cuda and x.dtype == y.dtype and x.is_contiguous() and x.shape == y.shape:
         return ops.add_relu_(y, x)
     return torch.relu(x + y)
 
@@ -172,7 +200,7 @@ class BasicEncoder(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = conv_norm_act(x, self.conv1, self.norm1, True)
         x = self.layer3(self.layer2(self.layer1(x)))
-        return self.conv2(x)
+        return conv_plain(x, self.conv2)
 
 
 class MultiBasicEncoder(nn.Module):
@@ -209,13 +237,13 @@ class MultiBasicEncoder(nn.Module):
     def forward(self, x: torch.Tensor, num_layers: int = 3):
         x = conv_norm_act(x, self.conv1, self.norm1, True)
         x = self.layer3(self.layer2(self.layer1(x)))
-        out08 = [f(x) for f in self.outputs08]
+        out08 = [conv_plain(f[0](x), f[1]) for f in self.outputs08]
         if num_layers == 1:
             return (out08,)
         y = self.layer4(x)
-        out16 = [f(y) for f in self.outputs16]
+        out16 = [conv_plain(f[0](y), f[1]) for f in self.outputs16]
         if num_layers == 2:
             return (out08, out16)
         z = self.layer5(y)
-        out32 = [f(z) for f in self.outputs32]
+        out32 = [conv_plain(z, f) for f in self.outputs32]
         return (out08, out16, out32)

@@ -21,14 +21,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import BasicEncoder, MultiBasicEncoder, fused_passes
+from .layers import BasicEncoder, MultiBasicEncoder, conv_plain, fused_passes
 from .update import BasicMultiUpdateBlock, BasicUpdateBlock
-
-
-def _autocast(dtype):
-    """Autocast context for the conv nets (the published models' ``mixed_precision``
-    switch; the reference leaves it off, so the default is full float32)."""
-    return torch.autocast(device_type="cuda", dtype=dtype, enabled=dtype is not None)
 
 
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
@@ -77,13 +71,19 @@ class RAFTFlow(nn.Module):
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=3)
         self.cnet = BasicEncoder(output_dim=c.hidden_dim + c.context_dim, norm_fn="batch", downsample=3)
         self.update_block = BasicUpdateBlock(c.corr_levels, c.corr_radius, hidden_dim=c.hidden_dim)
-        self.amp_dtype = None            # e.g. torch.bfloat16: experiment only, not the reference's precision
+        # The published models' ``mixed_precision`` switch (off in the reference,
+        # flow/flow_map_RAFT.py:38): float16 activations in the conv nets over float32
+        # master weights; correlation, lookup, coordinates and upsampling stay float32.
+        self.mixed_precision = False
+
+    def _act_dtype(self):
+        return torch.float16 if self.mixed_precision else torch.float32
 
     @torch.no_grad()
     def features(self, images: torch.Tensor) -> torch.Tensor:
         """Normalised images (B,3,H,W) -> pixel-major feature maps (B,H/8,W/8,256)."""
-        with _autocast(self.amp_dtype), fused_passes():
-            fmap = self.fnet(images)
+        with fused_passes():
+            fmap = self.fnet(images.to(self._act_dtype()))
         return pixel_major(fmap)
 
     @torch.no_grad()
@@ -106,8 +106,9 @@ class RAFTFlow(nn.Module):
         corr = ops.corr_volume_2d(fmap1, fmap2)
         pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
 
-        with _autocast(self.amp_dtype), fused_passes():
-            net, inp = torch.split(self.cnet(image1), [c.hidden_dim, c.context_dim], dim=1)
+        act = self._act_dtype()
+        with fused_passes():
+            net, inp = torch.split(self.cnet(image1.to(act)), [c.hidden_dim, c.context_dim], dim=1)
             net, inp = torch.tanh(net), torch.relu(inp)
 
         coords0 = coords_grid(B, H8, W8, image1.device)
@@ -118,8 +119,9 @@ class RAFTFlow(nn.Module):
         for it in range(iters):
             window = ops.corr_lookup_2d(pyramid, coords1.contiguous(), c.corr_radius)
             flow = coords1 - coords0
-            with _autocast(self.amp_dtype), fused_passes():
-                net, raw_mask, delta = self.update_block(net, inp, window, flow, want_mask=(it == iters - 1))
+            with fused_passes():
+                net, raw_mask, delta = self.update_block(net, inp, window.to(act), flow.to(act),
+                                                         want_mask=(it == iters - 1))
             coords1 = coords1 + delta.float()
         flow_low = (coords1 - coords0).contiguous()
         flow_up = ops.convex_upsample(flow_low, raw_mask.float().contiguous(), 8, mask_scale=0.25)
@@ -158,7 +160,7 @@ class RAFTStereo(nn.Module):
         self.context_zqr_convs = nn.ModuleList(
             [nn.Conv2d(context_dims[i], c.hidden_dims[i] * 3, 3, padding=1) for i in range(c.n_gru_layers)])
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=c.n_downsample)
-        self.amp_dtype = None
+        self.mixed_precision = False     # as in RAFTFlow (stereo/stereo_disparity_RAFT.py:43 leaves it off)
 
     @torch.no_grad()
     def forward(self, image1, image2, iters: int = 12, flow_init=None, normalized: bool = False):
@@ -172,13 +174,15 @@ class RAFTStereo(nn.Module):
             image2 = normalize_image(image2)
         B = image1.shape[0]
 
-        with _autocast(self.amp_dtype), fused_passes():
+        act = torch.float16 if self.mixed_precision else torch.float32
+        with fused_passes():
+            image1, image2 = image1.to(act), image2.to(act)
             cnet_list = self.cnet(image1, num_layers=c.n_gru_layers)
             both = self.fnet(torch.cat([image1, image2], dim=0))
             net_list = [torch.tanh(x[0]) for x in cnet_list]
             inp_list = [torch.relu(x[1]) for x in cnet_list]
             # the GRUs' context terms do not change across iterations: convolve once
-            inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
+            inp_list = [list(conv_plain(i, conv).split(split_size=conv.out_channels // 3, dim=1))
                         for i, conv in zip(inp_list, self.context_zqr_convs)]
         both = pixel_major(both)
         fmap1, fmap2 = both[:B], both[B:]
@@ -195,13 +199,14 @@ class RAFTStereo(nn.Module):
         for it in range(iters):
             window = ops.corr_lookup_1d(pyramid, coords1.contiguous(), c.corr_radius)
             flow = coords1 - coords0
-            if c.n_gru_layers == 3 and c.slow_fast_gru:
-                net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
-            if c.n_gru_layers >= 2 and c.slow_fast_gru:
-                net_list = self.update_block(net_list, inp_list, iter32=c.n_gru_layers == 3, iter16=True,
-                                             iter08=False, update=False)
-            with _autocast(self.amp_dtype), fused_passes():
-                net_list, raw_mask, delta = self.update_block(net_list, inp_list, window, flow,
+            with fused_passes():
+                if c.n_gru_layers == 3 and c.slow_fast_gru:
+                    net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False,
+                                                 update=False)
+                if c.n_gru_layers >= 2 and c.slow_fast_gru:
+                    net_list = self.update_block(net_list, inp_list, iter32=c.n_gru_layers == 3, iter16=True,
+                                                 iter08=False, update=False)
+                net_list, raw_mask, delta = self.update_block(net_list, inp_list, window.to(act), flow.to(act),
                                                               iter32=c.n_gru_layers == 3, iter16=c.n_gru_layers >= 2,
                                                               want_mask=(it == iters - 1))
             delta = delta.float()

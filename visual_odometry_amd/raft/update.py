@@ -14,16 +14,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .layers import conv_act, fused_on
+from .layers import conv_act, conv_plain, fused_on, weight_for
 
 
-def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Conv2d) -> torch.Tensor:
-    """cat(convz.weight, convr.weight): z and r read the same input, so one convolution
-    with 2C output channels replaces two.  Cached; rebuilt if a weight changes or moves."""
-    key = (convz.weight._version, convz.weight.data_ptr(), convr.weight._version, convr.weight.data_ptr())
+def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Conv2d, dtype) -> torch.Tensor:
+    """cat(convz.weight, convr.weight) in ``dtype``: z and r read the same input, so one
+    convolution with 2C output channels replaces two.  Cached; rebuilt if a weight
+    changes or moves."""
+    key = (convz.weight._version, convz.weight.data_ptr(), convr.weight._version, convr.weight.data_ptr(), dtype)
     cached = getattr(owner, "_vo_zr_" + tag, None)
     if cached is None or cached[0] != key:
-        cached = (key, torch.cat([convz.weight, convr.weight], dim=0).contiguous())
+        cached = (key, torch.cat([convz.weight, convr.weight], dim=0).detach().to(dtype).contiguous())
         setattr(owner, "_vo_zr_" + tag, cached)
     return cached[1]
 
@@ -31,9 +32,9 @@ def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Co
 def _fused_gru_step(owner, tag, buf, h, C, convz, convr, convq, ctx=(None, None, None), h_copy=None):
     """One GRU step on buf = [h | x] (B, C+X, H, W).  buf's first C channels are
     overwritten with r*h for the q convolution; returns the new hidden state."""
-    zr = F.conv2d(buf, _merged_zr_weight(owner, tag, convz, convr), None, padding=convz.padding)
+    zr = F.conv2d(buf, _merged_zr_weight(owner, tag, convz, convr, buf.dtype), None, padding=convz.padding)
     z = ops.gru_gates(zr, convz.bias, convr.bias, ctx[0], ctx[1], h, buf[:, :C])
-    q = F.conv2d(buf, convq.weight, None, padding=convq.padding)
+    q = F.conv2d(buf, weight_for(convq, buf), None, padding=convq.padding)
     return ops.gru_update(q, convq.bias, ctx[2], z, h, torch.empty_like(h), h_copy)
 
 
@@ -45,7 +46,7 @@ class FlowHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return self.conv2(conv_act(x, self.conv1))
+        return conv_plain(conv_act(x, self.conv1), self.conv2)
 
 
 class SepConvGRU(nn.Module):
@@ -71,7 +72,7 @@ class SepConvGRU(nn.Module):
 
     def forward(self, h, x):
         """``x`` may be a tensor or a list of tensors that together form the input."""
-        if fused_on() and h.is_cuda and h.dtype == torch.float32:
+        if fused_on() and h.is_cuda and h.dtype in (torch.float32, torch.float16):
             parts = list(x) if isinstance(x, (list, tuple)) else [x]
             C = h.shape[1]
             buf = torch.cat([h] + parts, dim=1)                          # the only copy of the step
@@ -94,7 +95,7 @@ class ConvGRU(nn.Module):
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
 
     def forward(self, h, cz, cr, cq, *x_list):
-        if fused_on() and h.is_cuda and h.dtype == torch.float32:
+        if fused_on() and h.is_cuda and h.dtype in (torch.float32, torch.float16):
             buf = torch.cat([h] + list(x_list), dim=1)
             return _fused_gru_step(self, "0", buf, h, h.shape[1], self.convz, self.convr, self.convq, (cz, cr, cq))
         x = torch.cat(x_list, dim=1)
@@ -163,7 +164,7 @@ class BasicUpdateBlock(nn.Module):
         else:
             net = self.gru(net, torch.cat([inp, motion], dim=1))
         delta_flow = self.flow_head(net)
-        raw_mask = self.mask[2](conv_act(net, self.mask[0])) if want_mask else None      # caller scales by 0.25
+        raw_mask = conv_plain(conv_act(net, self.mask[0]), self.mask[2]) if want_mask else None   # caller scales by 0.25
         return net, raw_mask, delta_flow
 
 
@@ -172,7 +173,7 @@ def pool2x(x):
 
 
 def interp(x, dest):
-    if fused_on() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():
+    if fused_on() and x.is_cuda and x.dtype in (torch.float32, torch.float16) and x.is_contiguous():
         return ops.resize_bilinear(x, dest.shape[2:])
     return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
 
@@ -215,5 +216,5 @@ class BasicMultiUpdateBlock(nn.Module):
         if not update:
             return net
         delta_flow = self.flow_head(net[0])
-        raw_mask = self.mask[2](conv_act(net[0], self.mask[0])) if want_mask else None   # caller scales by 0.25
+        raw_mask = conv_plain(conv_act(net[0], self.mask[0]), self.mask[2]) if want_mask else None   # caller scales by 0.25
         return net, raw_mask, delta_flow

@@ -32,14 +32,6 @@ def _device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def _pad_amounts(ht: int, wd: int, divis_by: int):
-    """Replicate padding up to a multiple of ``divis_by``, split evenly with the odd
-    pixel at the far side (the published InputPadder's default mode)."""
-    ph = (((ht // divis_by) + 1) * divis_by - ht) % divis_by
-    pw = (((wd // divis_by) + 1) * divis_by - wd) % divis_by
-    return [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
-
-
 def _unpad(x: torch.Tensor, pads) -> torch.Tensor:
     ht, wd = x.shape[-2:]
     return x[..., pads[2]:ht - pads[3], pads[0]:wd - pads[1]]
@@ -77,7 +69,8 @@ def gray_batch_to_rgb(frames: torch.Tensor) -> torch.Tensor:
 
 
 class HipOpticalFlowRAFT(OpticalFlowInterface):
-    def __init__(self, checkpoint: Optional[str] = None, rectification=None, iters: int = 32, seed: int = 0):
+    def __init__(self, checkpoint: Optional[str] = None, rectification=None, iters: int = 32, seed: int = 0,
+                 mixed_precision: bool = False):
         self.device = _device()
         self.iters = iters
         self.flow = None
@@ -87,6 +80,7 @@ class HipOpticalFlowRAFT(OpticalFlowInterface):
         if checkpoint is not None:
             load_checkpoint(self.model, checkpoint, self.device)
         self.model.to(self.device).eval()
+        self.model.mixed_precision = bool(mixed_precision)      # flow/flow_map_RAFT.py:38 passes False
 
     def compute_flow(self, img1, img2) -> np.ndarray:
         if img1 is None or img2 is None:
@@ -101,7 +95,7 @@ class HipOpticalFlowRAFT(OpticalFlowInterface):
 
     def compute_flow_batch(self, image1: torch.Tensor, image2: torch.Tensor, fmap1=None, fmap2=None) -> torch.Tensor:
         """(B,3,H,W) float 0..255 GPU images -> flow (B,2,H,W) float32 on the GPU."""
-        pads = _pad_amounts(image1.shape[-2], image1.shape[-1], 8)
+        pads = ops.pad_amounts(image1.shape[-2], image1.shape[-1], 8)
         if any(pads):
             image1 = F.pad(image1, pads, mode="replicate")
             image2 = F.pad(image2, pads, mode="replicate")
@@ -121,7 +115,7 @@ class HipOpticalFlowRAFT(OpticalFlowInterface):
 
 class HipDisparityRAFT(StereoDisparityInterface):
     def __init__(self, checkpoint: Optional[str] = None, rectification=None, iters: int = 32,
-                 config: Optional[RAFTStereoConfig] = None, seed: int = 1):
+                 config: Optional[RAFTStereoConfig] = None, seed: int = 1, mixed_precision: bool = False):
         self.device = _device()
         self.iters = iters
         self.flow = None
@@ -131,6 +125,7 @@ class HipDisparityRAFT(StereoDisparityInterface):
         if checkpoint is not None:
             load_checkpoint(self.model, checkpoint, self.device)
         self.model.to(self.device).eval()
+        self.model.mixed_precision = bool(mixed_precision)      # stereo/stereo_disparity_RAFT.py:43 passes False
 
     def compute_disparity(self, img_left, img_right) -> np.ndarray:
         if img_left is None or img_right is None:
@@ -151,7 +146,7 @@ class HipDisparityRAFT(StereoDisparityInterface):
 
     def compute_disparity_batch(self, image1: torch.Tensor, image2: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) float 0..255 GPU images -> disparity (B,H,W) float32 (negative)."""
-        pads = _pad_amounts(image1.shape[-2], image1.shape[-1], 32)
+        pads = ops.pad_amounts(image1.shape[-2], image1.shape[-1], 32)
         if any(pads):
             image1 = F.pad(image1, pads, mode="replicate")
             image2 = F.pad(image2, pads, mode="replicate")
