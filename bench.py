@@ -65,8 +65,9 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
     }
 
 
-PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_pyramid_2d": "pyr2d", "vo_corr_lookup_2d": "lookup2d",
-            "vo_corr_lookup_1d": "lookup1d", "vo_instance_norm_relu": "instnorm", "vo_add_relu": "add_relu"}
+PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_corr_pyramid_2d": "pyr2d",
+            "vo_corr_pyramid_1d": "pyr1d", "vo_corr_lookup_2d": "lookup2d", "vo_corr_lookup_1d": "lookup1d",
+            "vo_instance_norm_relu": "instnorm"}
 
 
 def pmc_traffic(kernel: str, B: int, H: int, W: int):
@@ -83,6 +84,30 @@ def pmc_traffic(kernel: str, B: int, H: int, W: int):
     if not k:
         return None
     return (2.0 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
+
+
+def mixed_precision_leg(vo32, vo16, left, right, cached, steps):
+    """Secondary measurement, never the headline: the same step with float16 activations in
+    the conv nets (the published models' mixed_precision switch, which the reference leaves
+    off), its throughput and its deviation from the float32 path on the same frames."""
+    with torch.no_grad():
+        f32, d32 = vo32.flows(left), vo32.disparity_solver.compute_disparity_gray_batch(left[1:], right[1:])
+        f16, d16 = vo16.flows(left), vo16.disparity_solver.compute_disparity_gray_batch(left[1:], right[1:])
+    epe = (f16 - f32).pow(2).sum(1).sqrt().mean().item()
+    derr = (d16 - d32).abs().mean().item()
+    del f32, d32, f16, d16
+    for _ in range(2):
+        vo16.process_chunk(left, right, cached)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vo16.process_chunk(left, right, cached)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": (left.shape[0] - 1) / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt,
+            "dtype": "f16 activations, f32 weights/correlation/geometry",
+            "flow_epe_px_vs_f32": epe, "disparity_err_px_vs_f32": derr, "budget_px": 0.05,
+            "note": "not the reference's precision (mixed_precision=False there); reported beside, not as, the metric"}
 
 
 def cpu_baseline(vo, left, right, iters, cores):
@@ -121,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="frame pairs per step and per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="frame pairs per step and per GPU")
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -130,6 +155,10 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="let MIOpen benchmark its solvers per conv shape")
     ap.add_argument("--channels-last", action="store_true", help="run the conv nets in NHWC memory format")
     ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--mixed-precision", action="store_true",
+                    help="time the float16-activation path as the headline instead of float32 (not the reference's precision)")
+    ap.add_argument("--no-mixed-precision-leg", action="store_true",
+                    help="skip the secondary float16-activation measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,11 +178,14 @@ def main():
 
     H, W, B = args.height, args.width, args.batch
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
-    cfg = VOConfig(iters=args.iters,
-                   stereo=RAFTStereoConfig.realtime() if args.stereo == "realtime" else RAFTStereoConfig(),
-                   camera_offset=syn.CAMERA_OFFSET)
-    vo = VisualOdometry(cfg, syn.left_K(W / 640.0), syn.focal_length_px() * (W / 640.0), syn.baseline(),
-                        np.ones((H, W), bool), seed=0)
+    def make_vo(mixed):
+        cfg = VOConfig(iters=args.iters,
+                       stereo=RAFTStereoConfig.realtime() if args.stereo == "realtime" else RAFTStereoConfig(),
+                       camera_offset=syn.CAMERA_OFFSET, mixed_precision=mixed)
+        return VisualOdometry(cfg, syn.left_K(W / 640.0), syn.focal_length_px() * (W / 640.0), syn.baseline(),
+                              np.ones((H, W), bool), seed=0)
+
+    vo = make_vo(args.mixed_precision)
     n_kp = vo.keypoints.shape[0]
     if args.channels_last:
         vo.flow_solver.model.to(memory_format=torch.channels_last)
@@ -240,7 +272,8 @@ def main():
             "metric": "VO frame-pairs/sec at 640x480 (flow+stereo+pose)", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 activations, f32 weights/correlation/geometry" if args.mixed_precision else "f32",
+            "data": "synthetic",
             "config": {"workload": f"RAFT-Flow + RAFT-Stereo({args.stereo} args) {W}x{H}, {args.iters} iters, "
                                    f"{n_kp} grid keypoints, Kabsch pose; synthetic stereo frame pairs resident in HBM",
                        "pairs_per_step_per_gpu": B, "pairs_timed": pairs, "iters": args.iters,
@@ -252,6 +285,8 @@ def main():
             "kernels": kernels,
             "skipped_pairs_last_step": int(skipped.sum().item()),
         }
+        if world == 1 and not args.mixed_precision and not args.no_mixed_precision_leg:
+            out["mixed_precision"] = mixed_precision_leg(vo, make_vo(True), left, right, cached, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             cores = args.cpu_cores or min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(vo, left, right, args.iters, cores)
