@@ -48,6 +48,26 @@ int vo_prepare_images(const uint8_t* gray, float* out, int frames, int H, int W,
                       int pad_left, int pad_right, int pad_top, int pad_bottom,
                       int normalize, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Stereo rectification (stereo/stereo_rectification.py; the reference calls OpenCV).
+ *   vo_rectify_maps       cv2.initUndistortRectifyMap(K, D, R, P, size, CV_32FC1) (:38-39):
+ *                         for every rectified pixel the raw-image position, plumb-bob
+ *                         distortion (k1 k2 p1 p2 [k3 k4 k5 k6], n_dist of them), float64
+ *                         arithmetic, float32 maps (H,W).  K 3x3, R 3x3, P 3x4 row-major and
+ *                         the coefficients are HOST arrays.
+ *   vo_remap_bilinear_u8  cv2.remap(img, map_x, map_y, INTER_LINEAR) (:67-68, :113-114) for a
+ *                         batch of uint8 frames (frames,H,W) -> (frames,Ho,Wo) sharing one
+ *                         map pair (Ho,Wo): 5-bit fixed-point fractions, zero border.
+ *                         Wo must be a multiple of 4.
+ *   vo_erode3x3_u8        cv2.erode(mask, ones(3,3)) (:122-123) on a 0/1 mask; pixels outside
+ *                         the image do not erode.
+ * ------------------------------------------------------------------------- */
+int vo_rectify_maps(const double* K_host, const double* dist_host, int n_dist, const double* R_host,
+                    const double* P_host, float* map_x, float* map_y, int H, int W, void* stream);
+int vo_remap_bilinear_u8(const uint8_t* src, const float* map_x, const float* map_y, uint8_t* dst,
+                         int frames, int H, int W, int Ho, int Wo, void* stream);
+int vo_erode3x3_u8(const uint8_t* in, uint8_t* out, int H, int W, void* stream);
+
 /* Storage type of the conv nets' activation tensors in the fused passes below.  The
  * reference runs both networks in float32 (mixed_precision=False, flow/flow_map_RAFT.py:38,
  * stereo/stereo_disparity_RAFT.py:43); VO_F16 serves the published models'

@@ -142,3 +142,34 @@ def test_keypoint_tracks_through_the_pipeline(vo):
     assert (got_alive != alive).mean() < 0.02
     same = got_alive & alive
     assert np.abs(torch.cat([p[0] for p in parts]).cpu().numpy() - tracks)[same].max() < 1e-2
+
+
+def test_chunk_with_device_rectification(vo):
+    """Raw frames + a rectifier == rectifying first and running the plain pipeline."""
+    import yaml
+    from visual_odometry_amd.pipeline import VisualOdometry, VOConfig
+    from visual_odometry_amd.raft.models import RAFTStereoConfig
+    from visual_odometry_amd.rectification import HipStereoRectification
+
+    class P:
+        pass
+    d = yaml.safe_load(syn.RIG_YAML)
+    mk = lambda i: np.array([[i[0], 0, i[2]], [0, i[1], i[3]], [0, 0, 1.0]]) * np.array([[0.25], [0.25], [1.0]])
+    p = P()
+    p.K_l, p.K_r = mk(d["cam0"]["intrinsics"]), mk(d["cam1"]["intrinsics"])
+    p.D_l, p.D_r = np.array(d["cam0"]["distortion_coeffs"]), np.array(d["cam1"]["distortion_coeffs"])
+    T = np.array(d["cam1"]["T_cn_cnm1"]); p.R, p.T = T[:3, :3], T[:3, 3]
+    H, W, F = 120, 160, 4
+    p.resolution = (W, H)
+    rect = HipStereoRectification(p)
+    stereo_mask = rect.get_rectification_masks()[0]
+    cfg = VOConfig(iters=2, stereo=RAFTStereoConfig.realtime(), max_keypoints=80)
+    K = rect.P1[:3, :3]
+    args = (K, K[0, 0], float(np.linalg.norm(p.T)), stereo_mask)
+    left, right = syn.stereo_sequence(13, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    a = VisualOdometry(cfg, *args, seed=0, rectification=rect).process_chunk(l, r)
+    b = VisualOdometry(cfg, *args, seed=0).process_chunk(*rect.rectify_batch(l, r))
+    # MIOpen may pick another solver on the first call of a shape: rounding-level differences only
+    assert torch.equal(a[1], b[1]) and torch.allclose(a[0][~a[1]], b[0][~b[1]], atol=1e-3)
+    assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-3)

@@ -18,6 +18,9 @@ _P, _I, _L, _D, _F = c_void_p, c_int, c_int64, c_double, c_float
 
 # name -> argtypes; every function returns int except the two below.
 SIGNATURES = {
+    "vo_rectify_maps": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
+    "vo_remap_bilinear_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vo_erode3x3_u8": [_P, _P, _I, _I, _P],
     "vo_instance_norm_relu": [_P, _P, _L, _L, _F, _I, _I, _P],
     "vo_channel_affine_relu": [_P, _P, _P, _P, _L, _I, _L, _I, _I, _P],
     "vo_add_relu": [_P, _P, _L, _I, _P],

@@ -73,6 +73,51 @@ def _host9(Kinv) -> "ctypes.Array":
 
 # ------------------------------------------------------- fused encoder passes
 
+def _host_doubles(a, n=None, name="array"):
+    v = np.asarray(a, dtype=np.float64).reshape(-1)
+    if n is not None and v.size != n:
+        raise ValueError(f"{name} must have {n} elements")
+    return (ctypes.c_double * v.size)(*v.tolist())
+
+
+def rectify_maps(K, D, R, P, height: int, width: int, device) -> tuple:
+    """Sampling maps of one camera (cv2.initUndistortRectifyMap, CV_32FC1):
+    (map_x, map_y) float32 GPU tensors of shape (height, width)."""
+    d = np.asarray(D, dtype=np.float64).reshape(-1)
+    if d.size > 8:
+        raise ValueError("at most 8 distortion coefficients (k1 k2 p1 p2 k3 k4 k5 k6) are supported")
+    mx = torch.empty((height, width), device=device, dtype=torch.float32)
+    my = torch.empty_like(mx)
+    _call("vo_rectify_maps", _host_doubles(K, 9, "K"), _host_doubles(d) if d.size else None, int(d.size),
+          _host_doubles(R, 9, "R"), _host_doubles(np.asarray(P, dtype=np.float64)[:3, :4], 12, "P"),
+          mx.data_ptr(), my.data_ptr(), int(height), int(width), _stream())
+    return mx, my
+
+
+def remap_bilinear_u8(frames: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor) -> torch.Tensor:
+    """(F,H,W) uint8 frames resampled through one (Ho,Wo) map pair -> (F,Ho,Wo) uint8."""
+    if frames.dim() != 3:
+        raise ValueError("frames must be (F,H,W)")
+    if map_x.dim() != 2 or map_x.shape != map_y.shape:
+        raise ValueError("map_x and map_y must be (Ho,Wo)")
+    F_, H, W = frames.shape
+    Ho, Wo = map_x.shape
+    out = torch.empty((F_, Ho, Wo), device=frames.device, dtype=torch.uint8)
+    _call("vo_remap_bilinear_u8", _dev(frames, "frames", torch.uint8), _dev(map_x, "map_x", torch.float32),
+          _dev(map_y, "map_y", torch.float32), out.data_ptr(), F_, H, W, Ho, Wo, _stream(),
+          nbytes=F_ * (H * W + Ho * Wo) + 8 * Ho * Wo)
+    return out
+
+
+def erode3x3(mask: torch.Tensor) -> torch.Tensor:
+    """(H,W) uint8 0/1 mask -> its 3x3 erosion (outside pixels do not erode)."""
+    if mask.dim() != 2:
+        raise ValueError("mask must be (H,W)")
+    out = torch.empty_like(mask)
+    _call("vo_erode3x3_u8", _dev(mask, "mask", torch.uint8), out.data_ptr(), mask.shape[0], mask.shape[1], _stream())
+    return out
+
+
 VO_F32, VO_F16 = 0, 1        # storage codes of the fused conv-net passes (include/vo_hip.h)
 
 

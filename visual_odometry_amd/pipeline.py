@@ -60,8 +60,12 @@ class VisualOdometry:
     """All per-frame stages of the tracking loop on the current GPU."""
 
     def __init__(self, cfg: VOConfig, K: np.ndarray, focal_length_px, baseline, mask: np.ndarray,
-                 flow_checkpoint: Optional[str] = None, stereo_checkpoint: Optional[str] = None, seed: int = 0):
+                 flow_checkpoint: Optional[str] = None, stereo_checkpoint: Optional[str] = None, seed: int = 0,
+                 rectification=None):
         self.cfg = cfg
+        # optional HipStereoRectification: raw frames are rectified on the device, a chunk at a time
+        # (the reference rectifies inside each solver call, flow_map_RAFT.py:64-66, stereo_disparity_RAFT.py:74-75)
+        self.rectification = rectification
         self.flow_solver = HipOpticalFlowRAFT(flow_checkpoint, None, cfg.iters, seed=seed,
                                               mixed_precision=cfg.mixed_precision)
         self.disparity_solver = HipDisparityRAFT(stereo_checkpoint, None, cfg.iters, config=cfg.stereo, seed=seed + 1,
@@ -112,6 +116,8 @@ class VisualOdometry:
         last frame); without it frame 0's stereo pair is evaluated too."""
         if left.shape[0] < 2:
             raise ValueError("a chunk needs at least two frames")
+        if self.rectification is not None:
+            left, right = self.rectification.rectify_batch(left, right)
         if first_depth is None:
             depth = self.depth_maps(left, right)
         else:
@@ -140,6 +146,8 @@ class VisualOdometry:
         all k-frame segments in one launch -> (tracks (F-1,N,3) f64, alive (F-1,N) bool,
         reseeded (F-1) bool) on the GPU.  ``first_index`` is frame 0's index in the whole
         sequence (seedings fall on multiples of ``k`` of the GLOBAL index)."""
+        if self.rectification is not None:
+            left, right = self.rectification.rectify_batch(left, right)
         grid = self.pts_src.get_keypoints(None, max_keypoints)
         tracker = HipKeypointTracker(self._cam, grid, k=k, min_points=self.cfg.min_points)
         return tracker.track_batch(self.depth_maps(left, right), self.flows(left), first_index)
