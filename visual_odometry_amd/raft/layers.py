@@ -69,6 +69,11 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
 
 
 def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    if conv.kernel_size == (1, 1) and conv.stride != (1, 1) and conv.padding == (0, 0):
+        # a strided 1x1 convolution only ever reads the sampled pixels: gather them once and
+        # run a dense GEMM instead of MIOpen's strided 1x1 path (18 TFLOP/s on these shapes)
+        x = x[:, :, ::conv.stride[0], ::conv.stride[1]].contiguous()
+        return F.conv2d(x, weight_for(conv, x), None, 1, 0, conv.dilation, conv.groups)
     return F.conv2d(x, weight_for(conv, x), None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
