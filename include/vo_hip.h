@@ -97,6 +97,18 @@ int vo_resize_bilinear(const void* in, void* out, int64_t planes, int h, int w, 
                        void* stream);
 
 /* ---------------------------------------------------------------------------
+ * 3x3, stride 1, padding 1 float32 convolution (NCHW, no bias) as Winograd F(2x2,3x3)
+ * on the matrix cores: the dominant layer type of both networks' encoders and update
+ * blocks (models built at flow/flow_map_RAFT.py:42, stereo/stereo_disparity_RAFT.py:46).
+ *   vo_winograd_filter   weight (K,C,3,3) -> transformed filter, ceil(K/64)*64 * C * 16
+ *                        floats (do once per weight).  C must be a multiple of 8.
+ *   vo_conv3x3_winograd  x (N,C,H,W), transformed filter -> y (N,K,H,W).
+ * ------------------------------------------------------------------------- */
+int vo_winograd_filter(const float* weight, float* transformed, int K, int C, void* stream);
+int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int N, int C, int H, int W,
+                        int K, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Gate arithmetic of the convolutional GRUs (SepConvGRU of RAFT, ConvGRU of
  * RAFT-Stereo; same models, same call sites as above).  The z|r and q convolutions
  * run without bias in the framework; these passes add bias + context term, apply the

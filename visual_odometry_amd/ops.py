@@ -186,6 +186,29 @@ def resize_bilinear(x: torch.Tensor, size) -> torch.Tensor:
     return out
 
 
+def winograd_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,3,3) float32 weight -> the transformed filter vo_conv3x3_winograd consumes."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError("weight must be (K,C,3,3)")
+    K, C = weight.shape[:2]
+    if C % 8:
+        raise ValueError("the Winograd path needs a multiple of 8 input channels")
+    out = torch.empty(((K + 63) // 64 * 64 * C * 16,), device=weight.device, dtype=torch.float32)
+    _call("vo_winograd_filter", _dev(weight.detach(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    return out
+
+
+def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int) -> torch.Tensor:
+    """x (N,C,H,W) float32, transformed filter of a (K,C,3,3) weight -> conv2d(x, weight, padding=1)."""
+    N, C, H, W = x.shape
+    if transformed.numel() != (K + 63) // 64 * 64 * C * 16:
+        raise ValueError("transformed filter does not match (K, C)")
+    y = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    _call("vo_conv3x3_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), y.data_ptr(),
+          N, C, H, W, K, _stream(), nbytes=4 * (x.numel() + y.numel()))
+    return y
+
+
 def _slice(t, name: str, like: torch.Tensor | None = None):
     """A (B,C,H,W) GPU tensor whose (C,H,W) block is dense but whose batch items may be
     further apart (a channel slice of a bigger NCHW tensor) -> (ptr, batch stride)."""
