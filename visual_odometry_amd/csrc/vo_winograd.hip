@@ -24,6 +24,7 @@ constexpr int KB = 64;                 // output channels per workgroup
 constexpr int RAW_W = 20;              // padded row length of the raw patch (18 used)
 constexpr int RAW_C = 18 * RAW_W;      // floats per channel of the raw patch
 constexpr int V_FLOATS = 16 * CB * 64; // transformed chunk: [xi][c][tile]
+constexpr int RAW_FLOATS = CB * RAW_C;
 constexpr int RAW_PER_LANE = (CB * 18 * 18 + 511) / 512;   // 6
 
 // U = G g G^T for every (k, c), written as
@@ -61,9 +62,11 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g
 __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                    float* __restrict__ y, int C, int H, int W, int K, int blocks_x,
                                                    int blocks_y) {
-    __shared__ __align__(16) float lds[16 * 16 * 64];            // 64 KB: V | raw during the loop, M afterwards
+    // V and the raw patch are double-buffered (chunk c+1 is transformed while chunk c is
+    // multiplied); after the loop the first 64 KB hold M for the output transform.
+    __shared__ __align__(16) float lds[2 * V_FLOATS + 2 * RAW_FLOATS];
     float* Vs = lds;
-    float* raw = lds + V_FLOATS;
+    float* raw = lds + 2 * V_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
 
     // where this lane's raw-patch elements live (same for every chunk)
     int raw_lds[RAW_PER_LANE];
-    int64_t raw_glb[RAW_PER_LANE];
+    int raw_glb[RAW_PER_LANE];
 #pragma unroll
     for (int i = 0; i < RAW_PER_LANE; ++i) {
         const int idx = tid + i * 512;
@@ -85,13 +88,19 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
         const int gy = y0 + r, gx = x0 + col;
         const bool ok = idx < CB * 324 && gy >= 0 && gy < H && gx >= 0 && gx < W;
         raw_lds[i] = idx < CB * 324 ? c * RAW_C + r * RAW_W + col : -1;
-        raw_glb[i] = ok ? ((int64_t)c * H + gy) * W + gx : -1;
+        raw_glb[i] = ok ? (c * H + gy) * W + gx : -1;
     }
     float rv[RAW_PER_LANE];
     auto load_raw = [&](int chunk) {
         const float* xc = xn + (int64_t)chunk * CB * H * W;
 #pragma unroll
         for (int i = 0; i < RAW_PER_LANE; ++i) rv[i] = raw_glb[i] >= 0 ? xc[raw_glb[i]] : 0.0f;
+    };
+    auto store_raw = [&](int buf) {
+        float* rb = raw + buf * RAW_FLOATS;
+#pragma unroll
+        for (int i = 0; i < RAW_PER_LANE; ++i)
+            if (raw_lds[i] >= 0) rb[raw_lds[i]] = rv[i];
     };
     const float* Uw = Ug + (((int64_t)kb * nchunks) * 16 + 2 * wave) * 512 + lane;      // + chunk*8192 + (xl*2+i)*256 + ks*64
     float a_cur[16], a_nxt[16];
@@ -111,48 +120,38 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.0f;
 
-    load_raw(0);
-    load_a(0, a_nxt);
     const int tc = tid >> 6, tt = tid & 63, tty = tt >> 3, ttx = tt & 7;       // transform role: (channel, tile)
     const int kk = lane >> 5, nn = lane & 31;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    auto transform = [&](int buf) {                              // B^T d B of one (channel, tile)
+        const float* p = raw + buf * RAW_FLOATS + tc * RAW_C + (2 * tty) * RAW_W + 2 * ttx;
+        float d[4][4];
 #pragma unroll
-        for (int i = 0; i < RAW_PER_LANE; ++i)
-            if (raw_lds[i] >= 0) raw[raw_lds[i]] = rv[i];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
-        __syncthreads();
-        if (chunk + 1 < nchunks) { load_raw(chunk + 1); load_a(chunk + 1, a_nxt); }
-        {   // B^T d B of one (channel, tile)
-            const float* p = raw + tc * RAW_C + (2 * tty) * RAW_W + 2 * ttx;
-            float d[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float2 lo = *reinterpret_cast<const float2*>(p + r * RAW_W);
-                const float2 hi = *reinterpret_cast<const float2*>(p + r * RAW_W + 2);
-                d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = hi.x; d[r][3] = hi.y;
-            }
-            float t[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[0][j] = d[0][j] - d[2][j];
-                t[1][j] = d[1][j] + d[2][j];
-                t[2][j] = d[2][j] - d[1][j];
-                t[3][j] = d[1][j] - d[3][j];
-            }
-            float* vo = Vs + tc * 64 + tt;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                vo[(4 * a + 0) * (CB * 64)] = t[a][0] - t[a][2];
-                vo[(4 * a + 1) * (CB * 64)] = t[a][1] + t[a][2];
-                vo[(4 * a + 2) * (CB * 64)] = t[a][2] - t[a][1];
-                vo[(4 * a + 3) * (CB * 64)] = t[a][1] - t[a][3];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const float2 lo = *reinterpret_cast<const float2*>(p + r * RAW_W);
+            const float2 hi = *reinterpret_cast<const float2*>(p + r * RAW_W + 2);
+            d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = hi.x; d[r][3] = hi.y;
         }
-        __syncthreads();
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = d[0][j] - d[2][j];
+            t[1][j] = d[1][j] + d[2][j];
+            t[2][j] = d[2][j] - d[1][j];
+            t[3][j] = d[1][j] - d[3][j];
+        }
+        float* vo = Vs + buf * V_FLOATS + tc * 64 + tt;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            vo[(4 * a + 0) * (CB * 64)] = t[a][0] - t[a][2];
+            vo[(4 * a + 1) * (CB * 64)] = t[a][1] + t[a][2];
+            vo[(4 * a + 2) * (CB * 64)] = t[a][2] - t[a][1];
+            vo[(4 * a + 3) * (CB * 64)] = t[a][1] - t[a][3];
+        }
+    };
+    auto multiply = [&](int buf) {
 #pragma unroll
         for (int xl = 0; xl < 2; ++xl) {
-            const float* vb = Vs + (2 * wave + xl) * (CB * 64) + kk * 64 + 2 * nn;
+            const float* vb = Vs + buf * V_FLOATS + (2 * wave + xl) * (CB * 64) + kk * 64 + 2 * nn;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const float2 b = *reinterpret_cast<const float2*>(vb + ks * 128);
@@ -163,7 +162,29 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
                 acc[xl][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, acc[xl][1][1], 0, 0, 0);
             }
         }
+    };
+
+    load_raw(0);
+    load_a(0, a_nxt);
+    store_raw(0);
+    __syncthreads();
+    if (nchunks > 1) load_raw(1);
+    transform(0);
+    for (int chunk = 0; chunk + 1 < nchunks; ++chunk) {
+        const int cur = chunk & 1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
+        store_raw(cur ^ 1);                                      // chunk+1, prefetched one iteration ago
+        __syncthreads();                                         // V[cur] complete, raw[cur^1] visible
+        load_a(chunk + 1, a_nxt);
+        if (chunk + 2 < nchunks) load_raw(chunk + 2);
+        transform(cur ^ 1);                                      // chunk+1 -> V[cur^1], overlaps the MFMAs below
+        multiply(cur);
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
+    __syncthreads();
+    multiply((nchunks - 1) & 1);
 
     // output transform, 16 output channels per round: M[xi][kq][tile] through LDS
     float* yn = y + (int64_t)n * K * H * W;
