@@ -234,6 +234,8 @@ def main():
         recorded = sum(ev[2] for ev in evs)
         if recorded and "bytes" not in w:          # kernels whose work depends on the tensor they are handed
             w = {"launches": len(evs) // args.steps, "bytes": recorded / args.steps}
+            if sum(ev[3] for ev in evs):
+                w["flops"] = sum(ev[3] for ev in evs) / args.steps
         per_step_ms = sum(ms) / args.steps
         entry = {"launches_per_step": len(ms) // args.steps, "avg_us": 1e3 * sum(ms) / len(ms),
                  "ms_per_step": per_step_ms}
@@ -244,7 +246,8 @@ def main():
             entry["TFLOPs"] = w["flops"] / (per_step_ms * 1e-3) / 1e12
         kernels[name] = entry
     work = {k: (work[k] if k in work else {"launches": v["launches_per_step"],
-                                            "bytes": v.get("alg_GB_per_launch", 0) * 1e9 * v["launches_per_step"]})
+                                            "bytes": v.get("alg_GB_per_launch", 0) * 1e9 * v["launches_per_step"],
+                                            **({"flops": v["TFLOPs"] * 1e12 * v["ms_per_step"] * 1e-3} if "TFLOPs" in v else {})})
             for k, v in kernels.items()}
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     d = kernels[dom]
@@ -256,6 +259,10 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
     roofline["traffic"] = pmc_traffic(dom, B, H, W)
+    if dom == "vo_conv3x3_winograd":
+        # flops are the multiply-adds the kernel issues in the Winograd domain (4/9 of the direct form)
+        roofline["direct_equivalent_TFLOPs"] = d["TFLOPs"] * 2.25
+        roofline["note"] = "mean over all 3x3 layers of one step; traffic counters are collected per layer shape (DESIGN.md)"
     # the north star's one dense contraction, reported whether or not it dominates
     ck = kernels.get("vo_corr_volume_2d")
     roofline_corr = None

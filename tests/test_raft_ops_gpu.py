@@ -433,3 +433,40 @@ def test_mixed_precision_stays_within_the_flow_budget(vo):
         derr = (d16 - d32).abs().mean().item()
         assert epe < 0.05 and derr < 0.05, (epe, derr)
         assert epe > 0 and derr > 0            # the switch did change the arithmetic
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(2, 8, 16, 16, 64), (1, 16, 37, 53, 40), (2, 64, 60, 80, 126), (1, 24, 17, 16, 32),
+                                       (3, 128, 33, 47, 192), (1, 8, 1, 1, 33), (2, 96, 30, 40, 96)])
+def test_winograd_conv3x3_matches_direct_convolution(vo, N, C, H, W, K):
+    """The Winograd/MFMA 3x3 kernel against the float64 direct convolution: ragged image
+    sizes (partial 16x16 blocks), output channels that do not fill a 64-block, and
+    run-to-run identical results."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=50).to(DEV)
+    w = (_rand(K, C, 3, 3, seed=51) / (3 * C ** 0.5)).to(DEV)
+    U = ops.winograd_filter(w)
+    got = ops.conv3x3_winograd(x, U, K)
+    want = Fn.conv2d(x.double(), w.double(), None, 1, 1)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.equal(got, ops.conv3x3_winograd(x, U, K))
+    with pytest.raises(ValueError):
+        ops.winograd_filter(_rand(8, 6, 3, 3, seed=1).to(DEV))
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(x, U[:-1].contiguous(), K)
+
+
+def test_networks_agree_with_and_without_the_winograd_kernel(vo):
+    from visual_odometry_amd.raft import layers
+    from visual_odometry_amd.raft.models import RAFTFlow, RAFTStereo, RAFTStereoConfig
+    torch.manual_seed(11)
+    flow, stereo = RAFTFlow().to(DEV).eval(), RAFTStereo(RAFTStereoConfig.realtime()).to(DEV).eval()
+    a, b = (_rand(1, 3, 96, 128, seed=60) * 60 + 120).to(DEV), (_rand(1, 3, 96, 128, seed=61) * 60 + 120).to(DEV)
+    try:
+        layers.winograd_enabled(False)
+        f0, d0 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
+    finally:
+        layers.winograd_enabled(True)
+    f1, d1 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
+    assert (f1 - f0).abs().max().item() < 1e-4 and (d1 - d0).abs().max().item() < 1e-4

@@ -37,8 +37,9 @@ def set_recorder(rec):
     return old
 
 
-def _call(name: str, *args, nbytes: int = 0) -> None:
-    """``nbytes`` = algorithmic bytes of this launch (recorded for roofline reports)."""
+def _call(name: str, *args, nbytes: int = 0, flops: int = 0) -> None:
+    """``nbytes`` / ``flops`` = algorithmic bytes / matrix-core FLOPs of this launch (recorded
+    for roofline reports)."""
     if _recorder is None:
         _lib.call(name, *args)
         return
@@ -47,7 +48,7 @@ def _call(name: str, *args, nbytes: int = 0) -> None:
     start.record()
     _lib.call(name, *args)
     end.record()
-    _recorder.setdefault(name, []).append((start, end, nbytes))
+    _recorder.setdefault(name, []).append((start, end, nbytes, flops))
 
 
 def _dev(t: torch.Tensor, name: str, dtype: torch.dtype) -> int:
@@ -205,7 +206,8 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int) -> torc
         raise ValueError("transformed filter does not match (K, C)")
     y = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
     _call("vo_conv3x3_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), y.data_ptr(),
-          N, C, H, W, K, _stream(), nbytes=4 * (x.numel() + y.numel()))
+          N, C, H, W, K, _stream(), nbytes=4 * (x.numel() + y.numel()),
+          flops=2 * 16 * C * K * N * ((H + 1) // 2) * ((W + 1) // 2))       # transformed-domain multiply-adds
     return y
 
 

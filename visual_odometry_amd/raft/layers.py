@@ -68,13 +68,43 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+_WINOGRAD = True            # float32 3x3 stride-1 convolutions on the hand-written Winograd/MFMA kernel
+
+
+def winograd_enabled(on: bool) -> None:
+    """Switch the hand-written 3x3 kernel on or off (off: every convolution goes to MIOpen)."""
+    global _WINOGRAD
+    _WINOGRAD = bool(on)
+
+
+def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+                  groups: int = 1) -> torch.Tensor:
+    """Bias-free convolution inside the fused path: 3x3 / stride 1 / padding 1 float32 layers
+    with at least 32 output channels and a multiple of 8 input channels run on the
+    Winograd F(2x2,3x3) matrix-core kernel (transformed filter cached on the weight tensor),
+    everything else on MIOpen."""
+    if (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] % 8 == 0 and weight.shape[0] >= 32
+            and weight.shape[1] == x.shape[1]):
+        # the transformed filter rides on the weight tensor object itself (an address-keyed
+        # table would hand a new model the filters of a freed one)
+        key = (weight._version, weight.data_ptr())
+        cached = getattr(weight, "_vo_winograd", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.winograd_filter(weight.contiguous()))
+            weight._vo_winograd = cached
+        return ops.conv3x3_winograd(x, cached[1], weight.shape[0])
+    return F.conv2d(x, weight, None, stride, padding, dilation, groups)
+
+
 def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     if conv.kernel_size == (1, 1) and conv.stride != (1, 1) and conv.padding == (0, 0):
         # a strided 1x1 convolution only ever reads the sampled pixels: gather them once and
         # run a dense GEMM instead of MIOpen's strided 1x1 path (18 TFLOP/s on these shapes)
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]].contiguous()
         return F.conv2d(x, weight_for(conv, x), None, 1, 0, conv.dilation, conv.groups)
-    return F.conv2d(x, weight_for(conv, x), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return conv2d_nobias(x, weight_for(conv, x), conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .layers import conv_act, conv_plain, fused_on, weight_for
+from .layers import conv2d_nobias, conv_act, conv_plain, fused_on, weight_for
 
 
 def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Conv2d, dtype) -> torch.Tensor:
@@ -32,9 +32,9 @@ def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Co
 def _fused_gru_step(owner, tag, buf, h, C, convz, convr, convq, ctx=(None, None, None), h_copy=None):
     """One GRU step on buf = [h | x] (B, C+X, H, W).  buf's first C channels are
     overwritten with r*h for the q convolution; returns the new hidden state."""
-    zr = F.conv2d(buf, _merged_zr_weight(owner, tag, convz, convr, buf.dtype), None, padding=convz.padding)
+    zr = conv2d_nobias(buf, _merged_zr_weight(owner, tag, convz, convr, buf.dtype), (1, 1), convz.padding)
     z = ops.gru_gates(zr, convz.bias, convr.bias, ctx[0], ctx[1], h, buf[:, :C])
-    q = F.conv2d(buf, weight_for(convq, buf), None, padding=convq.padding)
+    q = conv2d_nobias(buf, weight_for(convq, buf), (1, 1), convq.padding)
     return ops.gru_update(q, convq.bias, ctx[2], z, h, torch.empty_like(h), h_copy)
 
 
