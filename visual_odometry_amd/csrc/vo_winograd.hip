@@ -28,8 +28,9 @@ constexpr int RAW_FLOATS = CB * RAW_C;
 constexpr int RAW_PER_LANE = (CB * 18 * 18 + 511) / 512;   // 6
 
 // U = G g G^T for every (k, c), written as
-//   Ug[kb][chunk][xi][i][ks][lane]:  k = kb*64 + i*32 + (lane & 31),  c = chunk*8 + 2*ks + (lane >> 5)
-// (zero where k >= K), i.e. in the order wave-level A fragments are consumed.
+//   Ug[kb][chunk][xi][i][lane][ks]:  k = kb*64 + i*32 + (lane & 31),  c = chunk*8 + 2*ks + (lane >> 5)
+// (zero where k >= K): the four A fragments a lane needs for one (position, k-tile, chunk)
+// are one 16-byte load.
 __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g, float* __restrict__ Ug, int K, int C,
                                                      int Kpad) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g
         const float u[4] = {u0, u1, u2, u3};
         for (int b = 0; b < 4; ++b) {
             const int xi = 4 * a + b;
-            const int64_t o = ((((((int64_t)kb * nchunks + chunk) * 16 + xi) * 2 + i) * 4 + ks) * 64) + kk * 32 + kl;
+            const int64_t o = ((((((int64_t)kb * nchunks + chunk) * 16 + xi) * 2 + i) * 64) + kk * 32 + kl) * 4 + ks;
             Ug[o] = u[b];
         }
     }
@@ -102,12 +103,15 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
         for (int i = 0; i < RAW_PER_LANE; ++i)
             if (raw_lds[i] >= 0) rb[raw_lds[i]] = rv[i];
     };
-    const float* Uw = Ug + (((int64_t)kb * nchunks) * 16 + 2 * wave) * 512 + lane;      // + chunk*8192 + (xl*2+i)*256 + ks*64
-    float a_cur[16], a_nxt[16];
+    const float* Uw = Ug + (((int64_t)kb * nchunks) * 16 + 2 * wave) * 512 + lane * 4;  // + chunk*8192 + (xl*2+i)*256
+    float a_cur[16], a_nxt[16];                                  // [(xl*2+i)*4 + ks]
     auto load_a = [&](int chunk, float* a) {
         const float* p = Uw + (int64_t)chunk * 8192;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = p[j * 64];
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(p + j * 256);
+            a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+        }
     };
 
     f32x16 acc[2][2][2];
@@ -178,8 +182,10 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
         __syncthreads();                                         // V[cur] complete, raw[cur^1] visible
         load_a(chunk + 1, a_nxt);
         if (chunk + 2 < nchunks) load_raw(chunk + 2);
-        transform(cur ^ 1);                                      // chunk+1 -> V[cur^1], overlaps the MFMAs below
-        multiply(cur);
+        // chunk+1 -> V[cur^1] and the MFMAs on V[cur] are independent: half of the waves take
+        // them in the opposite order, so LDS/VALU work and matrix work overlap on a SIMD
+        if (wave < 4) { transform(cur ^ 1); multiply(cur); }
+        else          { multiply(cur); transform(cur ^ 1); }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
