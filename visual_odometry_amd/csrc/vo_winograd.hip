@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g
 
 __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                    float* __restrict__ y, int C, int H, int W, int K, int blocks_x,
-                                                   int blocks_y) {
+                                                   int blocks_y, int kblocks) {
     // V and the raw patch are double-buffered (chunk c+1 is transformed while chunk c is
     // multiplied); after the loop the first 64 KB hold M for the output transform.
     __shared__ __align__(16) float lds[2 * V_FLOATS + 2 * RAW_FLOATS];
@@ -70,11 +70,18 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
     float* raw = lds + 2 * V_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
+    // The dispatcher deals consecutive workgroups round robin over the 8 XCDs.  Give each XCD
+    // one contiguous range of the (image, block row, block column, channel block) list, so
+    // that blocks sharing halo rows and 128-byte lines hit in the same L2.
+    int bid;
+    {
+        const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+        bid = (int)(((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3));
+    }
+    const int kb = bid % kblocks; bid /= kblocks;
     const int bx = bid % blocks_x; bid /= blocks_x;
     const int by = bid % blocks_y;
     const int n = bid / blocks_y;
-    const int kb = blockIdx.y;
     const int nchunks = C / CB;
     const int y0 = by * 16 - 1, x0 = bx * 16 - 1;                // top-left of the raw patch (padding 1)
     const float* xn = x + (int64_t)n * C * H * W;
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
 
     // output transform, 16 output channels per round: M[xi][kq][tile] through LDS
     float* yn = y + (int64_t)n * K * H * W;
+    const bool quad_store = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         __syncthreads();                                         // previous readers of lds are done
@@ -209,30 +217,41 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
                 *reinterpret_cast<float2*>(lds + (2 * wave + xl) * 1024 + kq * 64 + 2 * nn) = v;
             }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int idx = tid + r * 512;
-            const int t = idx & 63, kq = idx >> 6;
+        {   // one (channel, pair of horizontally adjacent tiles) per lane: 16 bytes per output row
+            const int tp = tid & 31, kq = tid >> 5;
+            const int t = 2 * tp;
             const int k = kb * KB + q * 16 + kq;
-            float m[16];
+            float m[2][16];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = lds[xi * 1024 + kq * 64 + t];
-            float s0[4], s1[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                s0[b] = m[b] + m[4 + b] + m[8 + b];
-                s1[b] = m[4 + b] - m[8 + b] - m[12 + b];
+            for (int xi = 0; xi < 16; ++xi) {
+                const float2 v = *reinterpret_cast<const float2*>(lds + xi * 1024 + kq * 64 + t);
+                m[0][xi] = v.x; m[1][xi] = v.y;
             }
-            const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-            const float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            float o[2][4];                                       // [row][x]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    s0[b] = m[j][b] + m[j][4 + b] + m[j][8 + b];
+                    s1[b] = m[j][4 + b] - m[j][8 + b] - m[j][12 + b];
+                }
+                o[0][2 * j] = s0[0] + s0[1] + s0[2]; o[0][2 * j + 1] = s0[1] - s0[2] - s0[3];
+                o[1][2 * j] = s1[0] + s1[1] + s1[2]; o[1][2 * j + 1] = s1[1] - s1[2] - s1[3];
+            }
             const int oy = by * 16 + 2 * (t >> 3), ox = bx * 16 + 2 * (t & 7);
             if (k < K && oy < H && ox < W) {
-                float* o = yn + ((int64_t)k * H + oy) * W + ox;
-                o[0] = y00;
-                if (ox + 1 < W) o[1] = y01;
-                if (oy + 1 < H) {
-                    o[W] = y10;
-                    if (ox + 1 < W) o[W + 1] = y11;
+                float* p = yn + ((int64_t)k * H + oy) * W + ox;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (oy + r >= H) break;
+                    if (quad_store) {                            // W % 4 == 0, y 16-byte aligned: ox + 3 < W always
+                        *reinterpret_cast<float4*>(p + (int64_t)r * W) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (ox + c < W) p[(int64_t)r * W + c] = o[r][c];
+                    }
                 }
             }
         }
@@ -260,9 +279,9 @@ extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, flo
     const int bx = (W + 15) / 16, by = (H + 15) / 16;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
-    if (blocks > 0x7fffffffLL || kblocks > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: grid too large");
-    wino_kernel<<<dim3((unsigned)blocks, (unsigned)kblocks), dim3(512), 0, vo_stream(stream)>>>(x, transformed, y, C, H, W, K,
-                                                                                               bx, by);
+    if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: grid too large");
+    wino_kernel<<<dim3((unsigned)(blocks * kblocks)), dim3(512), 0, vo_stream(stream)>>>(x, transformed, y, C, H, W, K, bx, by,
+                                                                                        kblocks);
     VO_CHECK_LAUNCH("vo_conv3x3_winograd");
     return VO_OK;
 }
