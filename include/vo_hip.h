@@ -102,10 +102,15 @@ int vo_resize_bilinear(const void* in, void* out, int64_t planes, int h, int w, 
  * blocks (models built at flow/flow_map_RAFT.py:42, stereo/stereo_disparity_RAFT.py:46).
  *   vo_winograd_filter   weight (K,C,3,3) -> transformed filter, ceil(K/64)*64 * C * 16
  *                        floats (do once per weight).  C must be a multiple of 8.
- *   vo_conv3x3_winograd  x (N,C,H,W), transformed filter -> y (N,K,H,W).
+ *   vo_conv3x3_winograd  x (N,C,H,W), transformed filter -> y (N,K,H,W), with an optional
+ *                        epilogue at the store: v = v*scale[k] + shift[k] (shift alone = bias;
+ *                        both = folded inference batch norm), ReLU when relu != 0, then the
+ *                        residual join v = max(v + skip, 0) with skip (N,K,H,W).  Any of
+ *                        scale / shift / skip may be NULL.
  * ------------------------------------------------------------------------- */
 int vo_winograd_filter(const float* weight, float* transformed, int K, int C, void* stream);
-int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int N, int C, int H, int W,
+int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, const float* scale,
+                        const float* shift, int relu, const float* skip, int N, int C, int H, int W,
                         int K, void* stream);
 
 /* ---------------------------------------------------------------------------

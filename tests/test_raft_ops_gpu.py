@@ -470,3 +470,25 @@ def test_networks_agree_with_and_without_the_winograd_kernel(vo):
         layers.winograd_enabled(True)
     f1, d1 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
     assert (f1 - f0).abs().max().item() < 1e-4 and (d1 - d0).abs().max().item() < 1e-4
+
+
+def test_winograd_fused_epilogue(vo):
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    N, C, H, W, K = 2, 16, 21, 28, 40
+    x, w = _rand(N, C, H, W, seed=70).to(DEV), (_rand(K, C, 3, 3, seed=71) / 12).to(DEV)
+    scale, shift, skip = _rand(K, seed=72).to(DEV), _rand(K, seed=73).to(DEV), _rand(N, K, H, W, seed=74).to(DEV)
+    U = ops.winograd_filter(w)
+    y = Fn.conv2d(x, w, None, 1, 1)
+    b = lambda v: v[None, :, None, None]
+    cases = [((None, shift, False, None), y + b(shift)), ((None, shift, True, None), torch.relu(y + b(shift))),
+             ((scale, shift, True, None), torch.relu(y * b(scale) + b(shift))),
+             ((scale, shift, True, skip), torch.relu(skip + torch.relu(y * b(scale) + b(shift)))),
+             ((None, None, True, skip), torch.relu(skip + torch.relu(y)))]
+    for args, want in cases:
+        got = ops.conv3x3_winograd(x, U, K, *args)
+        assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(x, U, K, scale, None)
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(x, U, K, None, shift[:-1].contiguous())

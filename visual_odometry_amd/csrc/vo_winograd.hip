@@ -60,9 +60,13 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g
     }
 }
 
+// Optional per-channel epilogue applied at the store: v = y*scale[k] + shift[k]; ReLU;
+// then the residual join max(v + skip, 0).  Null pointers / relu = 0 switch stages off.
+struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; };
+
 __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
-                                                   float* __restrict__ y, int C, int H, int W, int K, int blocks_x,
-                                                   int blocks_y, int kblocks) {
+                                                   float* __restrict__ y, Epilogue ep, int C, int H, int W, int K,
+                                                   int blocks_x, int blocks_y, int kblocks) {
     // V and the raw patch are double-buffered (chunk c+1 is transformed while chunk c is
     // multiplied); after the loop the first 64 KB hold M for the output transform.
     __shared__ __align__(16) float lds[2 * V_FLOATS + 2 * RAW_FLOATS];
@@ -241,7 +245,31 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
             }
             const int oy = by * 16 + 2 * (t >> 3), ox = bx * 16 + 2 * (t & 7);
             if (k < K && oy < H && ox < W) {
-                float* p = yn + ((int64_t)k * H + oy) * W + ox;
+                const int64_t off = ((int64_t)k * H + oy) * W + ox;
+                float* p = yn + off;
+                if (ep.shift) {
+                    const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift[k];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[r][c] = o[r][c] * sc + sh;
+                }
+                if (ep.relu) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[r][c] = fmaxf(o[r][c], 0.0f);
+                }
+                if (ep.skip) {
+                    const float* sp = ep.skip + (int64_t)n * K * H * W + off;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        if (oy + r >= H) break;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (ox + c < W) o[r][c] = fmaxf(o[r][c] + sp[(int64_t)r * W + c], 0.0f);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     if (oy + r >= H) break;
@@ -271,17 +299,20 @@ extern "C" int vo_winograd_filter(const float* weight, float* transformed, int K
     return VO_OK;
 }
 
-extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int N, int C, int H, int W, int K,
+extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, const float* scale,
+                                   const float* shift, int relu, const float* skip, int N, int C, int H, int W, int K,
                                    void* stream) {
     VO_REQUIRE(x && transformed && y, "vo_conv3x3_winograd: null pointer");
+    VO_REQUIRE(!scale || shift, "vo_conv3x3_winograd: scale without shift");
+    VO_REQUIRE(skip != y, "vo_conv3x3_winograd: skip must not alias the output");
     VO_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && K > 0, "vo_conv3x3_winograd: bad sizes");
     if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: C=%d is not a multiple of %d", C, CB);
     const int bx = (W + 15) / 16, by = (H + 15) / 16;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: grid too large");
-    wino_kernel<<<dim3((unsigned)(blocks * kblocks)), dim3(512), 0, vo_stream(stream)>>>(x, transformed, y, C, H, W, K, bx, by,
-                                                                                        kblocks);
+    wino_kernel<<<dim3((unsigned)(blocks * kblocks)), dim3(512), 0, vo_stream(stream)>>>(
+        x, transformed, y, Epilogue{scale, shift, skip, relu}, C, H, W, K, bx, by, kblocks);
     VO_CHECK_LAUNCH("vo_conv3x3_winograd");
     return VO_OK;
 }

@@ -199,14 +199,26 @@ def winograd_filter(weight: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int) -> torch.Tensor:
-    """x (N,C,H,W) float32, transformed filter of a (K,C,3,3) weight -> conv2d(x, weight, padding=1)."""
+def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+                     shift: torch.Tensor | None = None, relu: bool = False,
+                     skip: torch.Tensor | None = None) -> torch.Tensor:
+    """x (N,C,H,W) float32, transformed filter of a (K,C,3,3) weight -> conv2d(x, weight, padding=1),
+    optionally followed in the same kernel by *scale[k] + shift[k], ReLU and relu(. + skip)."""
     N, C, H, W = x.shape
     if transformed.numel() != (K + 63) // 64 * 64 * C * 16:
         raise ValueError("transformed filter does not match (K, C)")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    if scale is not None and shift is None:
+        raise ValueError("scale needs shift")
+    if skip is not None and tuple(skip.shape) != (N, K, H, W):
+        raise ValueError("skip must have the shape of the output")
     y = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
     _call("vo_conv3x3_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), y.data_ptr(),
-          N, C, H, W, K, _stream(), nbytes=4 * (x.numel() + y.numel()),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
+          _opt(skip, "skip", torch.float32), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() + y.numel() * (1 + (skip is not None))),
           flops=2 * 16 * C * K * N * ((H + 1) // 2) * ((W + 1) // 2))       # transformed-domain multiply-adds
     return y
 

@@ -63,6 +63,10 @@ def weight_for(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
 def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     """conv(x) with bias, weights cast to the activations' dtype when they differ."""
     if x.dtype == conv.weight.dtype:
+        if fused_on() and conv.bias is not None:
+            U = _winograd_filter_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if U is not None:
+                return ops.conv3x3_winograd(x, U, conv.out_channels, None, conv.bias, False)
         return conv(x)
     w = weight_for(conv, x)
     return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
@@ -77,25 +81,50 @@ def winograd_enabled(on: bool) -> None:
     _WINOGRAD = bool(on)
 
 
-def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
-                  groups: int = 1) -> torch.Tensor:
-    """Bias-free convolution inside the fused path: 3x3 / stride 1 / padding 1 float32 layers
-    with at least 32 output channels and a multiple of 8 input channels run on the
-    Winograd F(2x2,3x3) matrix-core kernel (transformed filter cached on the weight tensor),
-    everything else on MIOpen."""
-    if (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
+    """The cached transformed filter when this convolution can run on the Winograd F(2x2,3x3)
+    matrix-core kernel (3x3 / stride 1 / padding 1, float32, >= 32 output channels, input
+    channels a multiple of 8), else None."""
+    if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] % 8 == 0 and weight.shape[0] >= 32
             and weight.shape[1] == x.shape[1]):
-        # the transformed filter rides on the weight tensor object itself (an address-keyed
-        # table would hand a new model the filters of a freed one)
-        key = (weight._version, weight.data_ptr())
-        cached = getattr(weight, "_vo_winograd", None)
-        if cached is None or cached[0] != key:
-            cached = (key, ops.winograd_filter(weight.contiguous()))
-            weight._vo_winograd = cached
-        return ops.conv3x3_winograd(x, cached[1], weight.shape[0])
+        return None
+    # the transformed filter rides on the weight tensor object itself (an address-keyed
+    # table would hand a new model the filters of a freed one)
+    key = (weight._version, weight.data_ptr())
+    cached = getattr(weight, "_vo_winograd", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.winograd_filter(weight.contiguous()))
+        weight._vo_winograd = cached
+    return cached[1]
+
+
+def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+                  groups: int = 1) -> torch.Tensor:
+    """Bias-free convolution inside the fused path: eligible 3x3 layers on the Winograd
+    kernel, everything else on MIOpen."""
+    U = _winograd_filter_for(x, weight, stride, padding, dilation, groups)
+    if U is not None:
+        return ops.conv3x3_winograd(x, U, weight.shape[0])
     return F.conv2d(x, weight, None, stride, padding, dilation, groups)
+
+
+def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor, relu: bool, skip=None) -> torch.Tensor:
+    """act(conv(x) * scale[c] + shift[c]) [then relu(skip + .)] with the bias-free convolution:
+    inside the Winograd kernel's store when the layer is eligible, otherwise convolution +
+    one in-place pass."""
+    w = weight_for(conv, x)
+    U = _winograd_filter_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if U is not None and (skip is None or (skip.dtype == torch.float32 and skip.is_contiguous())):
+        return ops.conv3x3_winograd(x, U, w.shape[0], scale, shift, relu, skip)
+    y = _conv_nobias(x, conv)
+    if scale is None:
+        scale = getattr(conv, "_vo_ones", None)
+        if scale is None or scale.device != y.device:
+            scale = torch.ones(conv.out_channels, device=y.device, dtype=torch.float32)
+            conv._vo_ones = scale
+    return ops.channel_affine_relu_(y, scale, shift, relu, skip)
 
 
 def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
@@ -119,7 +148,7 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
             return ops.instance_norm_relu_(_conv_nobias(x, conv), norm.eps, relu, skip)
         if isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats:
             scale, shift = _folded_batch_norm(norm, conv.bias)
-            return ops.channel_affine_relu_(_conv_nobias(x, conv), scale, shift, relu, skip)
+            return conv_affine_act(x, conv, scale, shift, relu, skip)
     y = norm(conv(x))
     y = torch.relu_(y) if relu else y
     return y if skip is None else add_act(skip, y)
@@ -128,12 +157,7 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
 def conv_act(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     """relu(conv(x)); fused: bias-free convolution, then bias + ReLU in one in-place pass."""
     if _fusable(x) and conv.bias is not None:
-        y = _conv_nobias(x, conv)
-        ones = getattr(conv, "_vo_ones", None)
-        if ones is None or ones.device != y.device:
-            ones = torch.ones(conv.out_channels, device=y.device, dtype=torch.float32)
-            conv._vo_ones = ones
-        return ops.channel_affine_relu_(y, ones, conv.bias, True)
+        return conv_affine_act(x, conv, None, conv.bias, True)
     return torch.relu_(conv_plain(x, conv))
 
 
