@@ -113,6 +113,13 @@ int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, cons
                         const float* shift, int relu, const float* skip, int N, int C, int H, int W,
                         int K, void* stream);
 
+/* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
+ * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one
+ * plane per filter tap, planes (N, K*9, H, W) in (k, r, s) order; this pass adds the nine
+ * shifted planes and the bias: out[n,k,y,x] = bias[k] + sum_rs planes[n,(k*3+r)*3+s,y+r-1,x+s-1]. */
+int vo_shift_add_3x3(const float* planes, const float* bias, float* out, int N, int K, int H, int W,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------
  * Gate arithmetic of the convolutional GRUs (SepConvGRU of RAFT, ConvGRU of
  * RAFT-Stereo; same models, same call sites as above).  The z|r and q convolutions

@@ -492,3 +492,17 @@ def test_winograd_fused_epilogue(vo):
         ops.conv3x3_winograd(x, U, K, scale, None)
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(x, U, K, None, shift[:-1].contiguous())
+
+
+def test_small_output_conv_as_taps_plus_shift_add(vo):
+    import torch.nn as nn
+    from visual_odometry_amd.raft.layers import conv_plain, fused_passes
+    torch.manual_seed(2)
+    for (N, C, H, W, K) in [(2, 32, 13, 300, 2), (1, 256, 60, 80, 2), (2, 8, 5, 7, 3)]:
+        conv = nn.Conv2d(C, K, 3, padding=1).to(DEV)
+        x = _rand(N, C, H, W, seed=80).to(DEV)
+        with torch.no_grad():
+            want = conv(x)
+            with fused_passes():
+                got = conv_plain(x, conv)
+        assert got.shape == want.shape and (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())

@@ -216,3 +216,42 @@ extern "C" int vo_add_relu(void* a, const void* b, int64_t n, int dtype, void* s
     VO_CHECK_LAUNCH("vo_add_relu");
     return VO_OK;
 }
+
+namespace {
+
+// out[n,k,y,x] = bias[k] + sum_{r,s} P[n, (k*3+r)*3+s, y+r-1, x+s-1]  (zero outside the image):
+// the second half of a 3x3 convolution with very few output channels, whose first half is
+// a 1x1 convolution with 9K output channels (one plane per filter tap).  One lane per pixel.
+__global__ __launch_bounds__(256) void shift_add_kernel(const float* __restrict__ P, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int K, int H, int W) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int n = blockIdx.z / K, k = blockIdx.z % K;
+    if (x >= W) return;
+    const float* p = P + ((int64_t)n * K + k) * 9 * H * W;
+    float acc = bias ? bias[k] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y + r - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int xx = x + s - 1;
+            if (xx >= 0 && xx < W) acc += p[((int64_t)(r * 3 + s) * H + yy) * W + xx];
+        }
+    }
+    out[(((int64_t)n * K + k) * H + y) * W + x] = acc;
+}
+
+}  // namespace
+
+extern "C" int vo_shift_add_3x3(const float* planes, const float* bias, float* out, int N, int K, int H, int W,
+                                void* stream) {
+    VO_REQUIRE(planes && out, "vo_shift_add_3x3: null pointer");
+    VO_REQUIRE(N > 0 && K > 0 && H > 0 && W > 0, "vo_shift_add_3x3: bad sizes");
+    if (H > 65535 || (int64_t)N * K > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_shift_add_3x3: grid too large");
+    const dim3 grid((unsigned)vo_ceil_div(W, 256), (unsigned)H, (unsigned)(N * K));
+    shift_add_kernel<<<grid, dim3(256), 0, vo_stream(stream)>>>(planes, bias, out, K, H, W);
+    VO_CHECK_LAUNCH("vo_shift_add_3x3");
+    return VO_OK;
+}

@@ -223,6 +223,18 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
     return y
 
 
+def shift_add_3x3(planes: torch.Tensor, bias: torch.Tensor | None, K: int) -> torch.Tensor:
+    """planes (N, K*9, H, W): per-tap 1x1 products in (k, r, s) order -> the 3x3 / padding 1
+    convolution output (N, K, H, W) (+ bias)."""
+    N, K9, H, W = planes.shape
+    if K9 != 9 * K or (bias is not None and bias.numel() != K):
+        raise ValueError("planes must be (N, 9K, H, W) and bias (K)")
+    out = torch.empty((N, K, H, W), device=planes.device, dtype=torch.float32)
+    _call("vo_shift_add_3x3", _dev(planes, "planes", torch.float32), _opt(bias, "bias", torch.float32), out.data_ptr(),
+          N, K, H, W, _stream(), nbytes=4 * (planes.numel() + out.numel()))
+    return out
+
+
 def _slice(t, name: str, like: torch.Tensor | None = None):
     """A (B,C,H,W) GPU tensor whose (C,H,W) block is dense but whose batch items may be
     further apart (a channel slice of a bigger NCHW tensor) -> (ptr, batch stride)."""

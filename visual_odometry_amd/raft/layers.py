@@ -63,10 +63,22 @@ def weight_for(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
 def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     """conv(x) with bias, weights cast to the activations' dtype when they differ."""
     if x.dtype == conv.weight.dtype:
-        if fused_on() and conv.bias is not None:
+        if fused_on() and conv.bias is not None and x.dtype == torch.float32 and x.is_cuda:
             U = _winograd_filter_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if U is not None:
                 return ops.conv3x3_winograd(x, U, conv.out_channels, None, conv.bias, False)
+            if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+                    and conv.groups == 1 and conv.out_channels <= 4 and x.is_contiguous()):
+                # very few output channels (the flow heads): a 1x1 convolution with one output plane
+                # per filter tap (a skinny GEMM that reads x once), then one pass that adds the nine
+                # shifted planes -- MIOpen's 3x3 kernels cost as much here as for 64 output channels
+                key = (conv.weight._version, conv.weight.data_ptr())
+                cached = getattr(conv, "_vo_taps", None)
+                if cached is None or cached[0] != key:
+                    K, C = conv.weight.shape[:2]
+                    cached = (key, conv.weight.detach().permute(0, 2, 3, 1).reshape(K * 9, C, 1, 1).contiguous())
+                    conv._vo_taps = cached
+                return ops.shift_add_3x3(F.conv2d(x, cached[1]), conv.bias, conv.out_channels)
         return conv(x)
     w = weight_for(conv, x)
     return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
