@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frame pairs per step and per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frame pairs per step and per GPU")
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -262,7 +262,7 @@ def main():
     if dom == "vo_conv3x3_winograd":
         # flops are the multiply-adds the kernel issues in the Winograd domain (4/9 of the direct form)
         roofline["direct_equivalent_TFLOPs"] = d["TFLOPs"] * 2.25
-        roofline["note"] = "mean over all 3x3 layers of one step; traffic counters are collected per layer shape (DESIGN.md)"
+        roofline["note"] = "mean over all 3x3 layers of one step; achieved counts the multiply-adds issued in the Winograd domain, traffic is the mean over the same launches"
     # the north star's one dense contraction, reported whether or not it dominates
     ck = kernels.get("vo_corr_volume_2d")
     roofline_corr = None
