@@ -91,10 +91,11 @@ int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, int64_t hw,
 int vo_channel_affine_relu(void* x, const float* scale, const float* shift, const void* skip,
                            int64_t batch, int C, int64_t hw, int relu, int dtype, void* stream);
 int vo_add_relu(void* a, const void* b, int64_t n, int dtype, void* stream);
-/* (planes,h,w) -> (planes,H,W) bilinear, corner-aligned (align_corners=True): the
- * inter-level state exchange of RAFT-Stereo's multi-level GRU. */
-int vo_resize_bilinear(const void* in, void* out, int64_t planes, int h, int w, int H, int W, int dtype,
-                       void* stream);
+/* (batch,channels,h,w) -> (batch,channels,H,W) bilinear, corner-aligned (align_corners=True):
+ * the inter-level state exchange of RAFT-Stereo's multi-level GRU.  out may be a channel
+ * slice of a wider tensor: items out_batch_stride ELEMENTS apart (0 = dense). */
+int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_stride, int batch, int channels,
+                       int h, int w, int H, int W, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * 3x3, stride 1, padding 1 float32 convolution (NCHW, no bias) as Winograd F(2x2,3x3)
@@ -106,12 +107,15 @@ int vo_resize_bilinear(const void* in, void* out, int64_t planes, int h, int w, 
  *                        epilogue at the store: v = v*scale[k] + shift[k] (shift alone = bias;
  *                        both = folded inference batch norm), ReLU when relu != 0, then the
  *                        residual join v = max(v + skip, 0) with skip (N,K,H,W).  Any of
- *                        scale / shift / skip may be NULL.
+ *                        scale / shift / skip may be NULL.  y may be a channel slice of a
+ *                        wider NCHW tensor: consecutive items y_batch_stride ELEMENTS apart
+ *                        (0 = dense, K*H*W), so a consumer's concatenated input is written
+ *                        in place instead of being copied together.
  * ------------------------------------------------------------------------- */
 int vo_winograd_filter(const float* weight, float* transformed, int K, int C, void* stream);
-int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, const float* scale,
-                        const float* shift, int relu, const float* skip, int N, int C, int H, int W,
-                        int K, void* stream);
+int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int64_t y_batch_stride,
+                        const float* scale, const float* shift, int relu, const float* skip,
+                        int N, int C, int H, int W, int K, void* stream);
 
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one

@@ -119,19 +119,21 @@ __global__ __launch_bounds__(256) void add_relu_kernel(T* __restrict__ a, const 
 // One lane per 4 output pixels of a row; source rows are re-read from L2.
 template <typename T>
 __global__ __launch_bounds__(256) void resize_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t total,
-                                                     int h, int w, int H, int W, float sy, float sx) {
+                                                     int channels, int64_t out_batch_stride, int h, int w, int H, int W,
+                                                     float sy, float sx) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int wq = (W + 3) >> 2;
     const int xq = (int)(t % wq);
     const int y = (int)((t / wq) % H);
     const int64_t plane = t / ((int64_t)wq * H);
+    const int64_t b = plane / channels, c = plane - b * channels;
     const float fy = sy * (float)y;
     const int y0 = min((int)fy, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
     const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
     const T* r0 = in + (plane * h + y0) * (int64_t)w;
     const T* r1 = in + (plane * h + y1) * (int64_t)w;
-    T* o = out + (plane * H + y) * (int64_t)W + 4 * xq;
+    T* o = out + b * out_batch_stride + (c * H + y) * (int64_t)W + 4 * xq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int x = 4 * xq + i;
@@ -150,21 +152,25 @@ int check_dtype(const char* fn, int dtype) {
 
 }  // namespace
 
-extern "C" int vo_resize_bilinear(const void* in, void* out, int64_t planes, int h, int w, int H, int W, int dtype,
-                                  void* stream) {
+extern "C" int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_stride, int batch, int channels, int h,
+                                  int w, int H, int W, int dtype, void* stream) {
     VO_REQUIRE(in && out, "vo_resize_bilinear: null pointer");
-    VO_REQUIRE(planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "vo_resize_bilinear: bad sizes");
+    VO_REQUIRE(batch > 0 && channels > 0 && h > 0 && w > 0 && H > 0 && W > 0, "vo_resize_bilinear: bad sizes");
     if (int rc = check_dtype("vo_resize_bilinear", dtype)) return rc;
+    if (out_batch_stride == 0) out_batch_stride = (int64_t)channels * H * W;
+    VO_REQUIRE(out_batch_stride >= (int64_t)channels * H * W, "vo_resize_bilinear: out_batch_stride smaller than one item");
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f;
-    const int64_t total = planes * H * ((W + 3) / 4);
+    const int64_t total = (int64_t)batch * channels * H * ((W + 3) / 4);
     const int64_t blocks = vo_ceil_div(total, 256);
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_resize_bilinear: grid too large");
     const dim3 grid((unsigned)blocks);
     if (dtype == VO_F16)
-        resize_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((const __half*)in, (__half*)out, total, h, w, H, W, sy, sx);
+        resize_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((const __half*)in, (__half*)out, total, channels,
+                                                                        out_batch_stride, h, w, H, W, sy, sx);
     else
-        resize_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((const float*)in, (float*)out, total, h, w, H, W, sy, sx);
+        resize_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((const float*)in, (float*)out, total, channels,
+                                                                       out_batch_stride, h, w, H, W, sy, sx);
     VO_CHECK_LAUNCH("vo_resize_bilinear");
     return VO_OK;
 }

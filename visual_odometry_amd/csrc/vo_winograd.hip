@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g
 
 // Optional per-channel epilogue applied at the store: v = y*scale[k] + shift[k]; ReLU;
 // then the residual join max(v + skip, 0).  Null pointers / relu = 0 switch stages off.
-struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; };
+struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; };
 
 __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                    float* __restrict__ y, Epilogue ep, int C, int H, int W, int K,
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
     multiply((nchunks - 1) & 1);
 
     // output transform, 16 output channels per round: M[xi][kq][tile] through LDS
-    float* yn = y + (int64_t)n * K * H * W;
-    const bool quad_store = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    float* yn = y + (int64_t)n * ep.y_batch_stride;              // the output may be a channel slice of a wider tensor
+    const bool quad_store = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ep.y_batch_stride & 3) == 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         __syncthreads();                                         // previous readers of lds are done
@@ -299,20 +299,22 @@ extern "C" int vo_winograd_filter(const float* weight, float* transformed, int K
     return VO_OK;
 }
 
-extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, const float* scale,
-                                   const float* shift, int relu, const float* skip, int N, int C, int H, int W, int K,
-                                   void* stream) {
+extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int64_t y_batch_stride,
+                                   const float* scale, const float* shift, int relu, const float* skip, int N, int C,
+                                   int H, int W, int K, void* stream) {
     VO_REQUIRE(x && transformed && y, "vo_conv3x3_winograd: null pointer");
     VO_REQUIRE(!scale || shift, "vo_conv3x3_winograd: scale without shift");
     VO_REQUIRE(skip != y, "vo_conv3x3_winograd: skip must not alias the output");
     VO_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && K > 0, "vo_conv3x3_winograd: bad sizes");
+    if (y_batch_stride == 0) y_batch_stride = (int64_t)K * H * W;
+    VO_REQUIRE(y_batch_stride >= (int64_t)K * H * W, "vo_conv3x3_winograd: y_batch_stride smaller than one item");
     if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: C=%d is not a multiple of %d", C, CB);
     const int bx = (W + 15) / 16, by = (H + 15) / 16;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: grid too large");
     wino_kernel<<<dim3((unsigned)(blocks * kblocks)), dim3(512), 0, vo_stream(stream)>>>(
-        x, transformed, y, Epilogue{scale, shift, skip, relu}, C, H, W, K, bx, by, kblocks);
+        x, transformed, y, Epilogue{scale, shift, skip, relu, y_batch_stride}, C, H, W, K, bx, by, kblocks);
     VO_CHECK_LAUNCH("vo_conv3x3_winograd");
     return VO_OK;
 }

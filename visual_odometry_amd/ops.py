@@ -176,13 +176,18 @@ def add_relu_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return a
 
 
-def resize_bilinear(x: torch.Tensor, size) -> torch.Tensor:
-    """(B,C,h,w) -> (B,C,H,W), bilinear with align_corners=True."""
+def resize_bilinear(x: torch.Tensor, size, out: torch.Tensor | None = None) -> torch.Tensor:
+    """(B,C,h,w) -> (B,C,H,W), bilinear with align_corners=True.  ``out`` may be a channel
+    slice of a wider NCHW tensor (dense (C,H,W) blocks, any batch stride)."""
     B, C, h, w = x.shape
     H, W = int(size[0]), int(size[1])
     px, dt, es = _act(x, "x")
-    out = torch.empty((B, C, H, W), device=x.device, dtype=x.dtype)
-    _call("vo_resize_bilinear", px, out.data_ptr(), B * C, h, w, H, W, dt, _stream(),
+    if out is None:
+        out = torch.empty((B, C, H, W), device=x.device, dtype=x.dtype)
+    elif tuple(out.shape) != (B, C, H, W):
+        raise ValueError("out must be (B,C,H,W)")
+    po, so = _slice(out, "out", x)
+    _call("vo_resize_bilinear", px, po, so, B, C, h, w, H, W, dt, _stream(),
           nbytes=es * (x.numel() + out.numel()))
     return out
 
@@ -201,9 +206,10 @@ def winograd_filter(weight: torch.Tensor) -> torch.Tensor:
 
 def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: torch.Tensor | None = None,
                      shift: torch.Tensor | None = None, relu: bool = False,
-                     skip: torch.Tensor | None = None) -> torch.Tensor:
+                     skip: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """x (N,C,H,W) float32, transformed filter of a (K,C,3,3) weight -> conv2d(x, weight, padding=1),
-    optionally followed in the same kernel by *scale[k] + shift[k], ReLU and relu(. + skip)."""
+    optionally followed in the same kernel by *scale[k] + shift[k], ReLU and relu(. + skip).
+    ``out`` may be a channel slice of a wider NCHW tensor (dense (K,H,W) blocks, any batch stride)."""
     N, C, H, W = x.shape
     if transformed.numel() != (K + 63) // 64 * 64 * C * 16:
         raise ValueError("transformed filter does not match (K, C)")
@@ -214,13 +220,17 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
         raise ValueError("scale needs shift")
     if skip is not None and tuple(skip.shape) != (N, K, H, W):
         raise ValueError("skip must have the shape of the output")
-    y = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
-    _call("vo_conv3x3_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), y.data_ptr(),
+    if out is None:
+        out = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (N, K, H, W) or out.dtype != torch.float32:
+        raise ValueError("out must be float32 (N,K,H,W)")
+    py, sy = _slice(out, "out")
+    _call("vo_conv3x3_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), py, sy,
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
           _opt(skip, "skip", torch.float32), N, C, H, W, K, _stream(),
-          nbytes=4 * (x.numel() + y.numel() * (1 + (skip is not None))),
+          nbytes=4 * (x.numel() + out.numel() * (1 + (skip is not None))),
           flops=2 * 16 * C * K * N * ((H + 1) // 2) * ((W + 1) // 2))       # transformed-domain multiply-adds
-    return y
+    return out
 
 
 def shift_add_3x3(planes: torch.Tensor, bias: torch.Tensor | None, K: int) -> torch.Tensor:

@@ -122,21 +122,27 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     return F.conv2d(x, weight, None, stride, padding, dilation, groups)
 
 
-def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor, relu: bool, skip=None) -> torch.Tensor:
+def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor, relu: bool, skip=None,
+                    out: torch.Tensor | None = None) -> torch.Tensor:
     """act(conv(x) * scale[c] + shift[c]) [then relu(skip + .)] with the bias-free convolution:
     inside the Winograd kernel's store when the layer is eligible, otherwise convolution +
-    one in-place pass."""
+    one in-place pass.  ``out`` (optional) is a channel slice of a wider tensor -- the
+    consumer's concatenated input -- that receives the result."""
     w = weight_for(conv, x)
     U = _winograd_filter_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
     if U is not None and (skip is None or (skip.dtype == torch.float32 and skip.is_contiguous())):
-        return ops.conv3x3_winograd(x, U, w.shape[0], scale, shift, relu, skip)
+        return ops.conv3x3_winograd(x, U, w.shape[0], scale, shift, relu, skip, out)
     y = _conv_nobias(x, conv)
     if scale is None:
         scale = getattr(conv, "_vo_ones", None)
         if scale is None or scale.device != y.device:
             scale = torch.ones(conv.out_channels, device=y.device, dtype=torch.float32)
             conv._vo_ones = scale
-    return ops.channel_affine_relu_(y, scale, shift, relu, skip)
+    y = ops.channel_affine_relu_(y, scale, shift, relu, skip)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
@@ -166,11 +172,16 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
     return y if skip is None else add_act(skip, y)
 
 
-def conv_act(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    """relu(conv(x)); fused: bias-free convolution, then bias + ReLU in one in-place pass."""
+def conv_act(x: torch.Tensor, conv: nn.Conv2d, out: torch.Tensor | None = None) -> torch.Tensor:
+    """relu(conv(x)); fused: bias-free convolution with bias + ReLU in the kernel's store or in
+    one in-place pass.  ``out``: optional channel slice that receives the result."""
     if _fusable(x) and conv.bias is not None:
-        return conv_affine_act(x, conv, None, conv.bias, True)
-    return torch.relu_(conv_plain(x, conv))
+        return conv_affine_act(x, conv, None, conv.bias, True, None, out)
+    y = torch.relu_(conv_plain(x, conv))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def _folded_batch_norm(norm: nn.BatchNorm2d, conv_bias=None):

@@ -116,12 +116,13 @@ class RAFTFlow(nn.Module):
         if flow_init is not None:
             coords1 = coords1 + flow_init
         raw_mask = None
+        state = {}                                               # the GRU's input buffer lives across iterations
         for it in range(iters):
             window = ops.corr_lookup_2d(pyramid, coords1.contiguous(), c.corr_radius)
             flow = coords1 - coords0
             with fused_passes():
                 net, raw_mask, delta = self.update_block(net, inp, window.to(act), flow.to(act),
-                                                         want_mask=(it == iters - 1))
+                                                         want_mask=(it == iters - 1), state=state)
             coords1 = coords1 + delta.float()
         flow_low = (coords1 - coords0).contiguous()
         flow_up = ops.convex_upsample(flow_low, raw_mask.float().contiguous(), 8, mask_scale=0.25)
@@ -196,6 +197,7 @@ class RAFTStereo(nn.Module):
         if flow_init is not None:
             coords1 = coords1 + flow_init
         raw_mask = None
+        state = {}                                               # GRU input buffers live across iterations
         for it in range(iters):
             window = ops.corr_lookup_1d(pyramid, coords1.contiguous(), c.corr_radius)
             flow = coords1 - coords0
@@ -208,7 +210,7 @@ class RAFTStereo(nn.Module):
                                                  iter08=False, update=False)
                 net_list, raw_mask, delta = self.update_block(net_list, inp_list, window.to(act), flow.to(act),
                                                               iter32=c.n_gru_layers == 3, iter16=c.n_gru_layers >= 2,
-                                                              want_mask=(it == iters - 1))
+                                                              want_mask=(it == iters - 1), state=state)
             delta = delta.float()
             delta = torch.cat([delta[:, :1], torch.zeros_like(delta[:, 1:])], dim=1)   # epipolar: no y motion
             coords1 = coords1 + delta

@@ -70,14 +70,18 @@ class SepConvGRU(nn.Module):
         q = torch.tanh(convq(torch.cat([r * h, x], dim=1)))
         return (1 - z) * h + z * q
 
-    def forward(self, h, x):
-        """``x`` may be a tensor or a list of tensors that together form the input."""
+    def forward(self, h, x, buf=None):
+        """``x`` may be a tensor or a list of tensors that together form the input.  ``buf``
+        (fused path): a (B, C+X, H, W) buffer whose channels C.. already hold the input and
+        whose first C channels hold ``h``; it is left holding the NEW hidden state in its
+        first C channels, ready for the next iteration."""
         if fused_on() and h.is_cuda and h.dtype in (torch.float32, torch.float16):
-            parts = list(x) if isinstance(x, (list, tuple)) else [x]
             C = h.shape[1]
-            buf = torch.cat([h] + parts, dim=1)                          # the only copy of the step
+            if buf is None:
+                parts = list(x) if isinstance(x, (list, tuple)) else [x]
+                buf = torch.cat([h] + parts, dim=1)                      # the only copy of the step
             h = _fused_gru_step(self, "1", buf, h, C, self.convz1, self.convr1, self.convq1, h_copy=buf[:, :C])
-            return _fused_gru_step(self, "2", buf, h, C, self.convz2, self.convr2, self.convq2)
+            return _fused_gru_step(self, "2", buf, h, C, self.convz2, self.convr2, self.convq2, h_copy=buf[:, :C])
         if isinstance(x, (list, tuple)):
             x = torch.cat(list(x), dim=1)
         h = self._step(h, x, self.convz1, self.convr1, self.convq1)
@@ -94,10 +98,14 @@ class ConvGRU(nn.Module):
         self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
 
-    def forward(self, h, cz, cr, cq, *x_list):
+    def forward(self, h, cz, cr, cq, *x_list, buf=None):
+        """``buf`` (fused path): prepared (B, C+X, H, W) buffer as in SepConvGRU.forward."""
         if fused_on() and h.is_cuda and h.dtype in (torch.float32, torch.float16):
-            buf = torch.cat([h] + list(x_list), dim=1)
-            return _fused_gru_step(self, "0", buf, h, h.shape[1], self.convz, self.convr, self.convq, (cz, cr, cq))
+            C = h.shape[1]
+            if buf is None:
+                buf = torch.cat([h] + list(x_list), dim=1)
+            return _fused_gru_step(self, "0", buf, h, C, self.convz, self.convr, self.convq, (cz, cr, cq),
+                                   h_copy=buf[:, :C])
         x = torch.cat(x_list, dim=1)
         hx = torch.cat([h, x], dim=1)
         z = torch.sigmoid(self.convz(hx) + cz)
@@ -117,12 +125,18 @@ class FlowMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
-    def forward(self, flow, corr):
+    def forward(self, flow, corr, out=None):
+        """``out`` (fused path): channel slice (B,126,H,W) of the GRU's input buffer that
+        receives the motion features."""
+        if fused_on():
+            B, _, H, W = flow.shape
+            both = torch.empty((B, 192 + 64, H, W), device=flow.device, dtype=flow.dtype)    # [cor | flo], written in place
+            conv_act(conv_act(corr, self.convc1), self.convc2, out=both[:, :192])
+            conv_act(conv_act(flow, self.convf1), self.convf2, out=both[:, 192:])
+            return [conv_act(both, self.conv, out=out), flow]      # the GRU concatenates once, with its other inputs
         cor = conv_act(conv_act(corr, self.convc1), self.convc2)
         flo = conv_act(conv_act(flow, self.convf1), self.convf2)
         out = conv_act(torch.cat([cor, flo], dim=1), self.conv)
-        if fused_on():
-            return [out, flow]                       # the GRU concatenates once, with its other inputs
         return torch.cat([out, flow], dim=1)
 
 
@@ -137,12 +151,18 @@ class StereoMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(64, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 64, 128 - 2, 3, padding=1)
 
-    def forward(self, flow, corr):
+    def forward(self, flow, corr, out=None):
+        """``out`` (fused path): channel slice (B,126,H,W) of the GRU's input buffer that
+        receives the motion features."""
+        if fused_on():
+            B, _, H, W = flow.shape
+            both = torch.empty((B, 64 + 64, H, W), device=flow.device, dtype=flow.dtype)    # [cor | flo], written in place
+            conv_act(conv_act(corr, self.convc1), self.convc2, out=both[:, :64])
+            conv_act(conv_act(flow, self.convf1), self.convf2, out=both[:, 64:])
+            return [conv_act(both, self.conv, out=out), flow]      # the GRU concatenates once, with its other inputs
         cor = conv_act(conv_act(corr, self.convc1), self.convc2)
         flo = conv_act(conv_act(flow, self.convf1), self.convf2)
         out = conv_act(torch.cat([cor, flo], dim=1), self.conv)
-        if fused_on():
-            return [out, flow]                       # the GRU concatenates once, with its other inputs
         return torch.cat([out, flow], dim=1)
 
 
@@ -157,12 +177,28 @@ class BasicUpdateBlock(nn.Module):
         self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
                                   nn.Conv2d(256, 64 * 9, 1, padding=0))
 
-    def forward(self, net, inp, corr, flow, want_mask: bool = True):
-        motion = self.encoder(flow, corr)
-        if isinstance(motion, list):
-            net = self.gru(net, [inp] + motion)
+    def forward(self, net, inp, corr, flow, want_mask: bool = True, state=None):
+        """``state`` (fused path): a dict the caller keeps across the iterations of one forward
+        pass; it holds the GRU's input buffer [h | inp | motion | flow], in which only the
+        motion and flow channels are rewritten per iteration (h is left there by the GRU)."""
+        if fused_on() and state is not None and net.is_cuda:
+            C, X = net.shape[1], inp.shape[1]
+            buf = state.get("buf")
+            if buf is None:
+                B, _, H, W = net.shape
+                buf = torch.empty((B, C + X + 128, H, W), device=net.device, dtype=net.dtype)
+                buf[:, :C].copy_(net)
+                buf[:, C:C + X].copy_(inp)
+                state["buf"] = buf
+            self.encoder(flow, corr, out=buf[:, C + X:C + X + 126])
+            buf[:, C + X + 126:].copy_(flow)
+            net = self.gru(net, None, buf=buf)
         else:
-            net = self.gru(net, torch.cat([inp, motion], dim=1))
+            motion = self.encoder(flow, corr)
+            if isinstance(motion, list):
+                net = self.gru(net, [inp] + motion)
+            else:
+                net = self.gru(net, torch.cat([inp, motion], dim=1))
         delta_flow = self.flow_head(net)
         raw_mask = conv_plain(conv_act(net, self.mask[0]), self.mask[2]) if want_mask else None   # caller scales by 0.25
         return net, raw_mask, delta_flow
@@ -198,7 +234,7 @@ class BasicMultiUpdateBlock(nn.Module):
                                   nn.Conv2d(256, (factor ** 2) * 9, 1, padding=0))
 
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
-                want_mask: bool = True):
+                want_mask: bool = True, state=None):
         if iter32:
             net[2] = self.gru32(net[2], *(inp[2]), pool2x(net[1]))
         if iter16:
@@ -206,7 +242,23 @@ class BasicMultiUpdateBlock(nn.Module):
                 net[1] = self.gru16(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
             else:
                 net[1] = self.gru16(net[1], *(inp[1]), pool2x(net[0]))
-        if iter08:
+        if iter08 and fused_on() and state is not None and net[0].is_cuda:
+            # persistent input buffer [h | motion(126) | flow(2) | interp(net[1])]: producers write
+            # their channel slices in place, h is left there by the GRU of the previous iteration
+            C = net[0].shape[1]
+            buf = state.get("buf08")
+            if buf is None:
+                B, _, H, W = net[0].shape
+                extra = net[1].shape[1] if self.n_gru_layers > 1 else 0
+                buf = torch.empty((B, C + 128 + extra, H, W), device=net[0].device, dtype=net[0].dtype)
+                buf[:, :C].copy_(net[0])
+                state["buf08"] = buf
+            self.encoder(flow, corr, out=buf[:, C:C + 126])
+            buf[:, C + 126:C + 128].copy_(flow)
+            if self.n_gru_layers > 1:
+                ops.resize_bilinear(net[1], net[0].shape[2:], out=buf[:, C + 128:])
+            net[0] = self.gru08(net[0], *(inp[0]), buf=buf)
+        elif iter08:
             motion = self.encoder(flow, corr)
             motion = motion if isinstance(motion, list) else [motion]
             if self.n_gru_layers > 1:
