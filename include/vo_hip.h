@@ -88,6 +88,10 @@ enum { VO_F32 = 0, VO_F16 = 1 };
  * ------------------------------------------------------------------------- */
 int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, int64_t hw, float eps, int relu,
                           int dtype, void* stream);
+/* The same normalisation with the plane statistics already known (stats (planes,2) float64:
+ * sum, sum of squares, as vo_conv3x3_winograd accumulates them): one read-modify-write pass. */
+int vo_instance_norm_apply(void* x, const void* skip, const double* stats, int64_t planes, int64_t hw,
+                           float eps, int relu, int dtype, void* stream);
 int vo_channel_affine_relu(void* x, const float* scale, const float* shift, const void* skip,
                            int64_t batch, int C, int64_t hw, int relu, int dtype, void* stream);
 int vo_add_relu(void* a, const void* b, int64_t n, int dtype, void* stream);
@@ -110,12 +114,15 @@ int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_stride, int 
  *                        scale / shift / skip may be NULL.  y may be a channel slice of a
  *                        wider NCHW tensor: consecutive items y_batch_stride ELEMENTS apart
  *                        (0 = dense, K*H*W), so a consumer's concatenated input is written
- *                        in place instead of being copied together.
+ *                        in place instead of being copied together.  stats (N,K,2) float64
+ *                        or NULL: the kernel ADDS each (image, channel) plane's sum and sum of
+ *                        squares of the raw output (caller zeroes it; no epilogue then) --
+ *                        the statistics pass of a following instance norm, for free.
  * ------------------------------------------------------------------------- */
 int vo_winograd_filter(const float* weight, float* transformed, int K, int C, void* stream);
 int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int64_t y_batch_stride,
                         const float* scale, const float* shift, int relu, const float* skip,
-                        int N, int C, int H, int W, int K, void* stream);
+                        double* stats, int N, int C, int H, int W, int K, void* stream);
 
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one

@@ -506,3 +506,22 @@ def test_small_output_conv_as_taps_plus_shift_add(vo):
             with fused_passes():
                 got = conv_plain(x, conv)
         assert got.shape == want.shape and (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_instance_norm_from_convolution_statistics(vo):
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (3, 64, 60, 80, 64), (1, 8, 16, 16, 33)]:
+        x, w = _rand(N, C, H, W, seed=90).to(DEV), (_rand(K, C, 3, 3, seed=91) / 12).to(DEV)
+        skip = _rand(N, K, H, W, seed=92).to(DEV)
+        U = ops.winograd_filter(w)
+        stats = torch.zeros((N, K, 2), device=DEV, dtype=torch.float64)
+        y = ops.conv3x3_winograd(x, U, K, stats=stats)
+        ref_y = Fn.conv2d(x.double(), w.double(), None, 1, 1)
+        want_stats = torch.stack([ref_y.sum((2, 3)), (ref_y * ref_y).sum((2, 3))], dim=2)
+        assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
+        want = torch.relu(skip + torch.relu(Fn.instance_norm(ref_y.float(), eps=1e-5)))
+        got = ops.instance_norm_apply_(y, stats, 1e-5, True, skip)
+        assert (got - want).abs().max().item() < 5e-5
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(x, U, K, None, skip[0, :, 0, 0].contiguous(), False, None, None, stats)

@@ -75,6 +75,36 @@ __global__ __launch_bounds__(256) void instnorm_kernel(T* __restrict__ x, const 
     }
 }
 
+// Instance norm with known statistics: grid.y = plane, grid.x strides the plane.
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(T* __restrict__ x, const T* __restrict__ skip,
+                                                             const double* __restrict__ stats, int64_t hw, float eps,
+                                                             int relu) {
+    const int64_t plane = blockIdx.y;
+    const double mean = stats[2 * plane] / (double)hw;
+    double var = stats[2 * plane + 1] / (double)hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    T* p = x + plane * hw;
+    const T* q = skip ? skip + plane * hw : nullptr;
+    const int64_t n4 = aligned4<T>(p, q) ? (hw >> 2) : 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t; i < n4; i += stride) {
+        float4 v = vo_ld4<T>(p, i);
+        v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+        if (relu) v = relu4(v);
+        if (q) v = relu4(add4(v, vo_ld4<T>(q, i)));
+        vo_st4<T>(p, i, v);
+    }
+    for (int64_t i = (n4 << 2) + t; i < hw; i += stride) {
+        float v = (vo_ld1(p, i) - m) * r;
+        if (relu) v = fmaxf(v, 0.0f);
+        if (q) v = fmaxf(v + vo_ld1(q, i), 0.0f);
+        vo_st1(p, i, v);
+    }
+}
+
 // y = x * scale[c] + shift[c] (+ ReLU) (+ residual join): BatchNorm2d in inference with
 // the running statistics folded into scale / shift, or a convolution's bias + ReLU.
 // grid.y = plane, grid.x strides the plane.
@@ -187,6 +217,23 @@ extern "C" int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, 
     else
         instnorm_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, hw, eps, relu);
     VO_CHECK_LAUNCH("vo_instance_norm_relu");
+    return VO_OK;
+}
+
+extern "C" int vo_instance_norm_apply(void* x, const void* skip, const double* stats, int64_t planes, int64_t hw,
+                                      float eps, int relu, int dtype, void* stream) {
+    VO_REQUIRE(x && stats, "vo_instance_norm_apply: null pointer");
+    VO_REQUIRE(planes > 0 && hw > 0, "vo_instance_norm_apply: bad sizes");
+    if (int rc = check_dtype("vo_instance_norm_apply", dtype)) return rc;
+    if (planes > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_instance_norm_apply: more than 65535 planes");
+    int64_t bx = vo_ceil_div(vo_ceil_div(hw, 4), 256);
+    if (bx > 64) bx = 64;
+    const dim3 grid((unsigned)bx, (unsigned)planes);
+    if (dtype == VO_F16)
+        instnorm_apply_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, (const __half*)skip, stats, hw, eps, relu);
+    else
+        instnorm_apply_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, stats, hw, eps, relu);
+    VO_CHECK_LAUNCH("vo_instance_norm_apply");
     return VO_OK;
 }
 

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g
 
 // Optional per-channel epilogue applied at the store: v = y*scale[k] + shift[k]; ReLU;
 // then the residual join max(v + skip, 0).  Null pointers / relu = 0 switch stages off.
-struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; };
+struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; double* stats; };
 
 __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                    float* __restrict__ y, Epilogue ep, int C, int H, int W, int K,
@@ -244,6 +244,24 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
                 o[1][2 * j] = s1[0] + s1[1] + s1[2]; o[1][2 * j + 1] = s1[1] - s1[2] - s1[3];
             }
             const int oy = by * 16 + 2 * (t >> 3), ox = bx * 16 + 2 * (t & 7);
+            if (ep.stats) {
+                // per-(image, channel) sum and sum of squares of the raw convolution output, for a
+                // following instance norm: this lane's in-image values, reduced over the 32 lanes
+                // that share the channel, one pair of float64 atomics per channel and workgroup
+                float ps = 0.0f, pq = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (oy + r < H && ox + c < W) { ps += o[r][c]; pq += o[r][c] * o[r][c]; }
+#pragma unroll
+                for (int m2 = 16; m2 > 0; m2 >>= 1) { ps += __shfl_xor(ps, m2, VO_WAVE); pq += __shfl_xor(pq, m2, VO_WAVE); }
+                if (tp == 0 && k < K) {
+                    double* st = ep.stats + ((int64_t)n * K + k) * 2;
+                    atomicAdd(st, (double)ps);
+                    atomicAdd(st + 1, (double)pq);
+                }
+            }
             if (k < K && oy < H && ox < W) {
                 const int64_t off = ((int64_t)k * H + oy) * W + ox;
                 float* p = yn + off;
@@ -300,10 +318,11 @@ extern "C" int vo_winograd_filter(const float* weight, float* transformed, int K
 }
 
 extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int64_t y_batch_stride,
-                                   const float* scale, const float* shift, int relu, const float* skip, int N, int C,
-                                   int H, int W, int K, void* stream) {
+                                   const float* scale, const float* shift, int relu, const float* skip, double* stats,
+                                   int N, int C, int H, int W, int K, void* stream) {
     VO_REQUIRE(x && transformed && y, "vo_conv3x3_winograd: null pointer");
     VO_REQUIRE(!scale || shift, "vo_conv3x3_winograd: scale without shift");
+    VO_REQUIRE(!stats || (!shift && !relu && !skip), "vo_conv3x3_winograd: statistics are of the raw output, no epilogue with them");
     VO_REQUIRE(skip != y, "vo_conv3x3_winograd: skip must not alias the output");
     VO_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && K > 0, "vo_conv3x3_winograd: bad sizes");
     if (y_batch_stride == 0) y_batch_stride = (int64_t)K * H * W;
@@ -314,7 +333,7 @@ extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, flo
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: grid too large");
     wino_kernel<<<dim3((unsigned)(blocks * kblocks)), dim3(512), 0, vo_stream(stream)>>>(
-        x, transformed, y, Epilogue{scale, shift, skip, relu, y_batch_stride}, C, H, W, K, bx, by, kblocks);
+        x, transformed, y, Epilogue{scale, shift, skip, relu, y_batch_stride, stats}, C, H, W, K, bx, by, kblocks);
     VO_CHECK_LAUNCH("vo_conv3x3_winograd");
     return VO_OK;
 }

@@ -163,6 +163,13 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
     absorbs it into its shift.  Stock operators otherwise."""
     if _fusable(x) and (skip is None or (skip.is_cuda and skip.dtype == x.dtype and skip.is_contiguous())):
         if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
+            w = weight_for(conv, x)
+            U = _winograd_filter_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if U is not None and x.shape[0] * w.shape[0] <= 65535:
+                # the convolution's store accumulates the plane statistics: the norm is one pass
+                stats = torch.zeros((x.shape[0], w.shape[0], 2), device=x.device, dtype=torch.float64)
+                y = ops.conv3x3_winograd(x, U, w.shape[0], stats=stats)
+                return ops.instance_norm_apply_(y, stats, norm.eps, relu, skip)
             return ops.instance_norm_relu_(_conv_nobias(x, conv), norm.eps, relu, skip)
         if isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats:
             scale, shift = _folded_batch_norm(norm, conv.bias)
