@@ -118,11 +118,16 @@ int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_stride, int 
  *                        or NULL: the kernel ADDS each (image, channel) plane's sum and sum of
  *                        squares of the raw output (caller zeroes it; no epilogue then) --
  *                        the statistics pass of a following instance norm, for free.
+ *                        in_stats (N,C,2) float64 or NULL: the INPUT is normalised while it is
+ *                        staged, x^ = relu((x - mean)*rstd) per (image, channel) with the plane
+ *                        sums a producing launch left there (eps = in_eps; C <= 512): the
+ *                        instance norm + ReLU between two convolutions without its own pass.
  * ------------------------------------------------------------------------- */
 int vo_winograd_filter(const float* weight, float* transformed, int K, int C, void* stream);
 int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int64_t y_batch_stride,
                         const float* scale, const float* shift, int relu, const float* skip,
-                        double* stats, int N, int C, int H, int W, int K, void* stream);
+                        double* stats, const double* in_stats, float in_eps,
+                        int N, int C, int H, int W, int K, void* stream);
 
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one

@@ -525,3 +525,25 @@ def test_instance_norm_from_convolution_statistics(vo):
         assert (got - want).abs().max().item() < 5e-5
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(x, U, K, None, skip[0, :, 0, 0].contiguous(), False, None, None, stats)
+
+
+def test_winograd_normalises_its_input_on_load(vo):
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (2, 64, 33, 47, 64)]:
+        z = (_rand(N, C, H, W, seed=95, scale=2.0) + 0.7).to(DEV)           # a raw convolution output
+        w = (_rand(K, C, 3, 3, seed=96) / 12).to(DEV)
+        st = torch.stack([z.double().sum((2, 3)), (z.double() ** 2).sum((2, 3))], dim=2).contiguous()
+        got = ops.conv3x3_winograd(z, ops.winograd_filter(w), K, in_stats=st, in_eps=1e-5)
+        want = Fn.conv2d(torch.relu(Fn.instance_norm(z, eps=1e-5)), w, None, 1, 1)
+        assert (got - want).abs().max().item() < 3e-5 * max(1.0, want.abs().max().item())
+    # a residual block end to end, chained path against the stock operators
+    from visual_odometry_amd.raft.layers import ResidualBlock, fused_passes
+    torch.manual_seed(4)
+    blk = ResidualBlock(64, 64, "instance").to(DEV).eval()
+    x = torch.relu(_rand(2, 64, 37, 52, seed=97)).to(DEV)
+    with torch.no_grad():
+        a = blk(x)
+        with fused_passes():
+            b = blk(x)
+    assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())

@@ -26,6 +26,7 @@ constexpr int RAW_C = 18 * RAW_W;      // floats per channel of the raw patch
 constexpr int V_FLOATS = 16 * CB * 64; // transformed chunk: [xi][c][tile]
 constexpr int RAW_FLOATS = CB * RAW_C;
 constexpr int RAW_PER_LANE = (CB * 18 * 18 + 511) / 512;   // 6
+constexpr int MAX_NORM_C = 512;        // input channels supported by the normalise-on-load variant
 
 // U = G g G^T for every (k, c), written as
 //   Ug[kb][chunk][xi][i][lane][ks]:  k = kb*64 + i*32 + (lane & 31),  c = chunk*8 + 2*ks + (lane >> 5)
@@ -64,14 +65,21 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ g
 // then the residual join max(v + skip, 0).  Null pointers / relu = 0 switch stages off.
 struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; double* stats; };
 
+// Optional normalisation of the INPUT while it is staged: x^ = relu((x - mean) * rstd) per (image,
+// channel), mean / rstd from the plane sums a producing launch left in `stats` (N,C,2): the
+// instance norm + ReLU between two convolutions without a pass of its own.
+struct InputNorm { const double* stats; float eps; };
+
+template <bool NORM_IN>
 __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
-                                                   float* __restrict__ y, Epilogue ep, int C, int H, int W, int K,
-                                                   int blocks_x, int blocks_y, int kblocks) {
+                                                   float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H, int W,
+                                                   int K, int blocks_x, int blocks_y, int kblocks) {
     // V and the raw patch are double-buffered (chunk c+1 is transformed while chunk c is
     // multiplied); after the loop the first 64 KB hold M for the output transform.
-    __shared__ __align__(16) float lds[2 * V_FLOATS + 2 * RAW_FLOATS];
+    __shared__ __align__(16) float lds[2 * V_FLOATS + 2 * RAW_FLOATS + (NORM_IN ? 2 * MAX_NORM_C : 0)];
     float* Vs = lds;
     float* raw = lds + 2 * V_FLOATS;
+    float2* nrm = reinterpret_cast<float2*>(lds + 2 * V_FLOATS + 2 * RAW_FLOATS);     // (scale, shift) per input channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // The dispatcher deals consecutive workgroups round robin over the 8 XCDs.  Give each XCD
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
     // where this lane's raw-patch elements live (same for every chunk)
     int raw_lds[RAW_PER_LANE];
     int raw_glb[RAW_PER_LANE];
+    unsigned raw_ch = 0;                                         // channel within the chunk, 3 bits per element
 #pragma unroll
     for (int i = 0; i < RAW_PER_LANE; ++i) {
         const int idx = tid + i * 512;
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
         const bool ok = idx < CB * 324 && gy >= 0 && gy < H && gx >= 0 && gx < W;
         raw_lds[i] = idx < CB * 324 ? c * RAW_C + r * RAW_W + col : -1;
         raw_glb[i] = ok ? (c * H + gy) * W + gx : -1;
+        raw_ch |= (unsigned)(c & 7) << (3 * i);
     }
     float rv[RAW_PER_LANE];
     auto load_raw = [&](int chunk) {
@@ -108,11 +118,30 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < RAW_PER_LANE; ++i) rv[i] = raw_glb[i] >= 0 ? xc[raw_glb[i]] : 0.0f;
     };
-    auto store_raw = [&](int buf) {
+    if (NORM_IN) {
+        const double hw = (double)H * (double)W;
+        for (int c = tid; c < C; c += 512) {
+            const double* st = in.stats + ((int64_t)n * C + c) * 2;
+            const double mean = st[0] / hw;
+            double var = st[1] / hw - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float r = (float)(1.0 / sqrt(var + (double)in.eps));
+            nrm[c] = make_float2(r, -(float)mean * r);
+        }
+        __syncthreads();
+    }
+    auto store_raw = [&](int buf, int chunk) {
         float* rb = raw + buf * RAW_FLOATS;
 #pragma unroll
         for (int i = 0; i < RAW_PER_LANE; ++i)
-            if (raw_lds[i] >= 0) rb[raw_lds[i]] = rv[i];
+            if (raw_lds[i] >= 0) {
+                float v = rv[i];
+                if (NORM_IN) {                                   // padding stays zero: it pads the NORMALISED tensor
+                    const float2 ss = nrm[chunk * CB + ((raw_ch >> (3 * i)) & 7)];
+                    v = raw_glb[i] >= 0 ? fmaxf(v * ss.x + ss.y, 0.0f) : 0.0f;
+                }
+                rb[raw_lds[i]] = v;
+            }
     };
     const float* Uw = Ug + (((int64_t)kb * nchunks) * 16 + 2 * wave) * 512 + lane * 4;  // + chunk*8192 + (xl*2+i)*256
     float a_cur[16], a_nxt[16];                                  // [(xl*2+i)*4 + ks]
@@ -181,7 +210,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
 
     load_raw(0);
     load_a(0, a_nxt);
-    store_raw(0);
+    store_raw(0, 0);
     __syncthreads();
     if (nchunks > 1) load_raw(1);
     transform(0);
@@ -189,7 +218,7 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
         const int cur = chunk & 1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
-        store_raw(cur ^ 1);                                      // chunk+1, prefetched one iteration ago
+        store_raw(cur ^ 1, chunk + 1);                           // chunk+1, prefetched one iteration ago
         __syncthreads();                                         // V[cur] complete, raw[cur^1] visible
         load_a(chunk + 1, a_nxt);
         if (chunk + 2 < nchunks) load_raw(chunk + 2);
@@ -319,7 +348,8 @@ extern "C" int vo_winograd_filter(const float* weight, float* transformed, int K
 
 extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int64_t y_batch_stride,
                                    const float* scale, const float* shift, int relu, const float* skip, double* stats,
-                                   int N, int C, int H, int W, int K, void* stream) {
+                                   const double* in_stats, float in_eps, int N, int C, int H, int W, int K,
+                                   void* stream) {
     VO_REQUIRE(x && transformed && y, "vo_conv3x3_winograd: null pointer");
     VO_REQUIRE(!scale || shift, "vo_conv3x3_winograd: scale without shift");
     VO_REQUIRE(!stats || (!shift && !relu && !skip), "vo_conv3x3_winograd: statistics are of the raw output, no epilogue with them");
@@ -328,12 +358,20 @@ extern "C" int vo_conv3x3_winograd(const float* x, const float* transformed, flo
     if (y_batch_stride == 0) y_batch_stride = (int64_t)K * H * W;
     VO_REQUIRE(y_batch_stride >= (int64_t)K * H * W, "vo_conv3x3_winograd: y_batch_stride smaller than one item");
     if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: C=%d is not a multiple of %d", C, CB);
+    if (in_stats && C > MAX_NORM_C)
+        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: normalise-on-load supports at most %d input channels", MAX_NORM_C);
     const int bx = (W + 15) / 16, by = (H + 15) / 16;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd: grid too large");
-    wino_kernel<<<dim3((unsigned)(blocks * kblocks)), dim3(512), 0, vo_stream(stream)>>>(
-        x, transformed, y, Epilogue{scale, shift, skip, relu, y_batch_stride, stats}, C, H, W, K, bx, by, kblocks);
+    const dim3 grid((unsigned)(blocks * kblocks));
+    const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats};
+    if (in_stats)
+        wino_kernel<true><<<grid, dim3(512), 0, vo_stream(stream)>>>(x, transformed, y, ep, InputNorm{in_stats, in_eps}, C, H, W,
+                                                                     K, bx, by, kblocks);
+    else
+        wino_kernel<false><<<grid, dim3(512), 0, vo_stream(stream)>>>(x, transformed, y, ep, InputNorm{nullptr, 0.0f}, C, H, W,
+                                                                      K, bx, by, kblocks);
     VO_CHECK_LAUNCH("vo_conv3x3_winograd");
     return VO_OK;
 }

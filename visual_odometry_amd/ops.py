@@ -220,12 +220,15 @@ def winograd_filter(weight: torch.Tensor) -> torch.Tensor:
 def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: torch.Tensor | None = None,
                      shift: torch.Tensor | None = None, relu: bool = False,
                      skip: torch.Tensor | None = None, out: torch.Tensor | None = None,
-                     stats: torch.Tensor | None = None) -> torch.Tensor:
+                     stats: torch.Tensor | None = None, in_stats: torch.Tensor | None = None,
+                     in_eps: float = 1e-5) -> torch.Tensor:
     """x (N,C,H,W) float32, transformed filter of a (K,C,3,3) weight -> conv2d(x, weight, padding=1),
     optionally followed in the same kernel by *scale[k] + shift[k], ReLU and relu(. + skip).
     ``out`` may be a channel slice of a wider NCHW tensor (dense (K,H,W) blocks, any batch stride).
     ``stats``: zeroed float64 (N,K,2) that receives each plane's sum and sum of squares of the
-    raw output (for instance_norm_apply_; no epilogue in that case)."""
+    raw output (for instance_norm_apply_; no epilogue in that case).
+    ``in_stats``: such sums of the INPUT x (N,C,2): x is instance-normalised and ReLU-ed while it
+    is loaded, so the tensor between two convolutions needs no normalisation pass of its own."""
     N, C, H, W = x.shape
     if transformed.numel() != (K + 63) // 64 * 64 * C * 16:
         raise ValueError("transformed filter does not match (K, C)")
@@ -241,12 +244,15 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
     elif tuple(out.shape) != (N, K, H, W) or out.dtype != torch.float32:
         raise ValueError("out must be float32 (N,K,H,W)")
     py, sy = _slice(out, "out")
+    if in_stats is not None and in_stats.numel() != N * C * 2:
+        raise ValueError("in_stats must be (N,C,2) float64")
     if stats is not None:
         if stats.numel() != N * K * 2 or shift is not None or relu or skip is not None:
             raise ValueError("stats must be (N,K,2) float64 and excludes the epilogue")
     _call("vo_conv3x3_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), py, sy,
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
-          _opt(skip, "skip", torch.float32), _opt(stats, "stats", torch.float64), N, C, H, W, K, _stream(),
+          _opt(skip, "skip", torch.float32), _opt(stats, "stats", torch.float64),
+          _opt(in_stats, "in_stats", torch.float64), float(in_eps), N, C, H, W, K, _stream(),
           nbytes=4 * (x.numel() + out.numel() * (1 + (skip is not None))),
           flops=2 * 16 * C * K * N * ((H + 1) // 2) * ((W + 1) // 2))       # transformed-domain multiply-adds
     return out

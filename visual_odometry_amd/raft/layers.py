@@ -245,10 +245,36 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
+        chained = self._instance_norm_chain(x)
+        if chained is not None:
+            return chained
         y = conv_norm_act(x, self.conv1, self.norm1, True)
         if self.downsample is not None:
             x = conv_norm_act(x, self.downsample[0], self.norm3, False)
         return conv_norm_act(y, self.conv2, self.norm2, True, skip=x)        # relu(x + relu(norm2(conv2(y))))
+
+    def _instance_norm_chain(self, x):
+        """Both convolutions on the Winograd kernel with instance norm: conv1's store leaves
+        the plane sums of its raw output, conv2 normalises + ReLUs that output while loading
+        it and leaves its own sums, and one pass applies norm2 + ReLU + the residual join.
+        The normalised tensor between the two convolutions is never written."""
+        plain = lambda n: isinstance(n, nn.InstanceNorm2d) and not n.affine and not n.track_running_stats
+        if not (_fusable(x) and x.dtype == torch.float32 and self.downsample is None and plain(self.norm1)
+                and plain(self.norm2)):
+            return None
+        c1, c2 = self.conv1, self.conv2
+        U1 = _winograd_filter_for(x, c1.weight, c1.stride, c1.padding, c1.dilation, c1.groups)
+        if U1 is None or c2.in_channels > 512 or x.shape[0] * max(c1.out_channels, c2.out_channels) > 65535:
+            return None
+        st1 = torch.zeros((x.shape[0], c1.out_channels, 2), device=x.device, dtype=torch.float64)
+        y1 = ops.conv3x3_winograd(x, U1, c1.out_channels, stats=st1)
+        U2 = _winograd_filter_for(y1, c2.weight, c2.stride, c2.padding, c2.dilation, c2.groups)
+        if U2 is None:
+            y1 = ops.instance_norm_apply_(y1, st1, self.norm1.eps, True)
+            return conv_norm_act(y1, c2, self.norm2, True, skip=x)
+        st2 = torch.zeros((x.shape[0], c2.out_channels, 2), device=x.device, dtype=torch.float64)
+        y2 = ops.conv3x3_winograd(y1, U2, c2.out_channels, stats=st2, in_stats=st1, in_eps=self.norm1.eps)
+        return ops.instance_norm_apply_(y2, st2, self.norm2.eps, True, x)
 
 
 def _init_weights(module: nn.Module):
