@@ -168,7 +168,7 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TORCHELASTIC_RUN_ID"):       # launched by torch.distributed.run (any world size)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
