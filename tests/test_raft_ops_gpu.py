@@ -547,3 +547,29 @@ def test_winograd_normalises_its_input_on_load(vo):
         with fused_passes():
             b = blk(x)
     assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
+
+
+def test_kernels_write_channel_slices_in_place(vo):
+    """Winograd convolution and bilinear resize writing straight into a channel slice of a
+    wider tensor (the consumer's concatenated input): neighbours untouched, values equal."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    N, C, H, W, K = 2, 16, 18, 24, 40
+    x, w = _rand(N, C, H, W, seed=100).to(DEV), (_rand(K, C, 3, 3, seed=101) / 12).to(DEV)
+    bias = _rand(K, seed=102).to(DEV)
+    wide = torch.full((N, 7 + K + 5, H, W), 3.25, device=DEV)
+    got = ops.conv3x3_winograd(x, ops.winograd_filter(w), K, None, bias, True, out=wide[:, 7:7 + K])
+    want = torch.relu(Fn.conv2d(x, w, bias, 1, 1))
+    assert got.data_ptr() == wide[:, 7:7 + K].data_ptr()
+    assert (wide[:, 7:7 + K] - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.all(wide[:, :7] == 3.25) and torch.all(wide[:, 7 + K:] == 3.25)
+    small = _rand(N, 6, 9, 12, seed=103).to(DEV)
+    wide = torch.full((N, 10, H, W), -1.5, device=DEV)
+    ops.resize_bilinear(small, (H, W), out=wide[:, 2:8])
+    want = Fn.interpolate(small, (H, W), mode="bilinear", align_corners=True)
+    assert (wide[:, 2:8] - want).abs().max().item() < 1e-4
+    assert torch.all(wide[:, :2] == -1.5) and torch.all(wide[:, 8:] == -1.5)
+    with pytest.raises(ValueError):
+        ops.resize_bilinear(small, (H, W), out=wide[:, 2:7])
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(x, ops.winograd_filter(w), K, out=wide.permute(0, 1, 3, 2)[:, :K])

@@ -9,7 +9,6 @@ CPU tensor: there is deliberately no fallback path.
 from __future__ import annotations
 
 import ctypes
-import math
 
 import numpy as np
 import torch

@@ -27,7 +27,7 @@ import torch
 
 from . import ops
 from .geometry import (HipCameraRansacXform, HipCameraSvdXform, HipKeypoints3DFlow, HipKeypoints3DXform,
-                       HipKeypointTracker, HipStereoDepth, UniformKeyPoints)
+                       HipKeypointTracker, UniformKeyPoints)
 from .raft.models import RAFTStereoConfig
 from .raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT
 
