@@ -67,7 +67,7 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
 
 PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_corr_pyramid_2d": "pyr2d",
             "vo_corr_pyramid_1d": "pyr1d", "vo_corr_lookup_2d": "lookup2d", "vo_corr_lookup_1d": "lookup1d",
-            "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd"}
+            "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4"}
 
 
 def pmc_traffic(kernel: str, B: int, H: int, W: int):
@@ -259,9 +259,10 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
     roofline["traffic"] = pmc_traffic(dom, B, H, W)
-    if dom == "vo_conv3x3_winograd":
-        # flops are the multiply-adds the kernel issues in the Winograd domain (4/9 of the direct form)
-        roofline["direct_equivalent_TFLOPs"] = d["TFLOPs"] * 2.25
+    if dom in ("vo_conv3x3_winograd", "vo_conv3x3_winograd4"):
+        # flops are the multiply-adds the kernel issues in the Winograd domain: 16 per 2x2 outputs
+        # (4/9 of the direct form) for F(2x2,3x3), 36 per 4x4 outputs (1/4) for F(4x4,3x3)
+        roofline["direct_equivalent_TFLOPs"] = d["TFLOPs"] * (2.25 if dom == "vo_conv3x3_winograd" else 4.0)
         roofline["note"] = "mean over all 3x3 layers of one step; achieved counts the multiply-adds issued in the Winograd domain, traffic is the mean over the same launches"
     # the north star's one dense contraction, reported whether or not it dominates
     ck = kernels.get("vo_corr_volume_2d")

@@ -128,6 +128,16 @@ int vo_conv3x3_winograd(const float* x, const float* transformed, float* y, int6
                         const float* scale, const float* shift, int relu, const float* skip,
                         double* stats, const double* in_stats, float in_eps,
                         int N, int C, int H, int W, int K, void* stream);
+/* The same convolution as Winograd F(4x4,3x3): 36 instead of 64 transformed-domain
+ * multiplies per 16 output pixels and channel pair, at a rounding error about twenty times
+ * that of the direct sum (1e-5 of the largest output; still float32 arithmetic throughout).
+ * Arguments, epilogue and statistics exactly as above; the transformed filter holds
+ * ceil(K/64)*64 * C * 36 floats and is NOT interchangeable with vo_winograd_filter's. */
+int vo_winograd4_filter(const float* weight, float* transformed, int K, int C, void* stream);
+int vo_conv3x3_winograd4(const float* x, const float* transformed, float* y, int64_t y_batch_stride,
+                         const float* scale, const float* shift, int relu, const float* skip,
+                         double* stats, const double* in_stats, float in_eps,
+                         int N, int C, int H, int W, int K, void* stream);
 
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one

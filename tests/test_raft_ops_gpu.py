@@ -435,21 +435,26 @@ def test_mixed_precision_stays_within_the_flow_budget(vo):
         assert epe > 0 and derr > 0            # the switch did change the arithmetic
 
 
+WINO_TOL = {2: 2e-5, 4: 1e-4}      # relative to the largest output value
+
+
 @pytest.mark.parametrize("N,C,H,W,K", [(2, 8, 16, 16, 64), (1, 16, 37, 53, 40), (2, 64, 60, 80, 126), (1, 24, 17, 16, 32),
-                                       (3, 128, 33, 47, 192), (1, 8, 1, 1, 33), (2, 96, 30, 40, 96)])
-def test_winograd_conv3x3_matches_direct_convolution(vo, N, C, H, W, K):
-    """The Winograd/MFMA 3x3 kernel against the float64 direct convolution: ragged image
-    sizes (partial 16x16 blocks), output channels that do not fill a 64-block, and
-    run-to-run identical results."""
+                                       (3, 128, 33, 47, 192), (1, 8, 1, 1, 33), (2, 96, 30, 40, 96), (1, 40, 70, 100, 72)])
+@pytest.mark.parametrize("tile", [2, 4])
+def test_winograd_conv3x3_matches_direct_convolution(vo, N, C, H, W, K, tile):
+    """The Winograd/MFMA 3x3 kernels, F(2x2,3x3) and F(4x4,3x3), against the float64 direct
+    convolution: ragged image sizes (partial blocks), output channels that do not fill a
+    64-block, and run-to-run identical results.  Tolerance: 2e-5 / 1e-4 of the largest output
+    (the larger tile's transforms multiply by up to 8, measured error 1e-5)."""
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops
     x = _rand(N, C, H, W, seed=50).to(DEV)
     w = (_rand(K, C, 3, 3, seed=51) / (3 * C ** 0.5)).to(DEV)
-    U = ops.winograd_filter(w)
+    U = ops.winograd_filter(w, tile)
     got = ops.conv3x3_winograd(x, U, K)
     want = Fn.conv2d(x.double(), w.double(), None, 1, 1)
     assert got.shape == want.shape
-    assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() < WINO_TOL[tile] * max(1.0, want.abs().max().item())
     assert torch.equal(got, ops.conv3x3_winograd(x, U, K))
     with pytest.raises(ValueError):
         ops.winograd_filter(_rand(8, 6, 3, 3, seed=1).to(DEV))
@@ -457,7 +462,11 @@ def test_winograd_conv3x3_matches_direct_convolution(vo, N, C, H, W, K):
         ops.conv3x3_winograd(x, U[:-1].contiguous(), K)
 
 
-def test_networks_agree_with_and_without_the_winograd_kernel(vo):
+@pytest.mark.parametrize("tile", [2, 4, 0])
+def test_networks_agree_with_and_without_the_winograd_kernel(vo, tile):
+    """Flow and disparity with every 3x3 layer on MIOpen against the Winograd kernels: forced
+    F(2x2,3x3), forced F(4x4,3x3) and the per-shape choice.  Through three update iterations the
+    larger tile's rounding shows as at most a few 1e-4 px."""
     from visual_odometry_amd.raft import layers
     from visual_odometry_amd.raft.models import RAFTFlow, RAFTStereo, RAFTStereoConfig
     torch.manual_seed(11)
@@ -468,17 +477,23 @@ def test_networks_agree_with_and_without_the_winograd_kernel(vo):
         f0, d0 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
     finally:
         layers.winograd_enabled(True)
-    f1, d1 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
-    assert (f1 - f0).abs().max().item() < 1e-4 and (d1 - d0).abs().max().item() < 1e-4
+    try:
+        layers.winograd_tile(tile)
+        f1, d1 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
+    finally:
+        layers.winograd_tile(0)
+    tol = 1e-4 if tile == 2 else 2e-3
+    assert (f1 - f0).abs().max().item() < tol and (d1 - d0).abs().max().item() < tol
 
 
-def test_winograd_fused_epilogue(vo):
+@pytest.mark.parametrize("tile", [2, 4])
+def test_winograd_fused_epilogue(vo, tile):
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops
     N, C, H, W, K = 2, 16, 21, 28, 40
     x, w = _rand(N, C, H, W, seed=70).to(DEV), (_rand(K, C, 3, 3, seed=71) / 12).to(DEV)
     scale, shift, skip = _rand(K, seed=72).to(DEV), _rand(K, seed=73).to(DEV), _rand(N, K, H, W, seed=74).to(DEV)
-    U = ops.winograd_filter(w)
+    U = ops.winograd_filter(w, tile)
     y = Fn.conv2d(x, w, None, 1, 1)
     b = lambda v: v[None, :, None, None]
     cases = [((None, shift, False, None), y + b(shift)), ((None, shift, True, None), torch.relu(y + b(shift))),
@@ -487,7 +502,7 @@ def test_winograd_fused_epilogue(vo):
              ((None, None, True, skip), torch.relu(skip + torch.relu(y)))]
     for args, want in cases:
         got = ops.conv3x3_winograd(x, U, K, *args)
-        assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+        assert (got - want).abs().max().item() < WINO_TOL[tile] * max(1.0, want.abs().max().item())
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(x, U, K, scale, None)
     with pytest.raises(ValueError):
@@ -508,13 +523,14 @@ def test_small_output_conv_as_taps_plus_shift_add(vo):
         assert got.shape == want.shape and (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
 
-def test_instance_norm_from_convolution_statistics(vo):
+@pytest.mark.parametrize("tile", [2, 4])
+def test_instance_norm_from_convolution_statistics(vo, tile):
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops
     for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (3, 64, 60, 80, 64), (1, 8, 16, 16, 33)]:
         x, w = _rand(N, C, H, W, seed=90).to(DEV), (_rand(K, C, 3, 3, seed=91) / 12).to(DEV)
         skip = _rand(N, K, H, W, seed=92).to(DEV)
-        U = ops.winograd_filter(w)
+        U = ops.winograd_filter(w, tile)
         stats = torch.zeros((N, K, 2), device=DEV, dtype=torch.float64)
         y = ops.conv3x3_winograd(x, U, K, stats=stats)
         ref_y = Fn.conv2d(x.double(), w.double(), None, 1, 1)
@@ -522,34 +538,41 @@ def test_instance_norm_from_convolution_statistics(vo):
         assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
         want = torch.relu(skip + torch.relu(Fn.instance_norm(ref_y.float(), eps=1e-5)))
         got = ops.instance_norm_apply_(y, stats, 1e-5, True, skip)
-        assert (got - want).abs().max().item() < 5e-5
+        assert (got - want).abs().max().item() < (5e-5 if tile == 2 else 3e-4)
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(x, U, K, None, skip[0, :, 0, 0].contiguous(), False, None, None, stats)
 
 
-def test_winograd_normalises_its_input_on_load(vo):
+@pytest.mark.parametrize("tile", [2, 4])
+def test_winograd_normalises_its_input_on_load(vo, tile):
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops
+    from visual_odometry_amd.raft import layers
     for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (2, 64, 33, 47, 64)]:
         z = (_rand(N, C, H, W, seed=95, scale=2.0) + 0.7).to(DEV)           # a raw convolution output
         w = (_rand(K, C, 3, 3, seed=96) / 12).to(DEV)
         st = torch.stack([z.double().sum((2, 3)), (z.double() ** 2).sum((2, 3))], dim=2).contiguous()
-        got = ops.conv3x3_winograd(z, ops.winograd_filter(w), K, in_stats=st, in_eps=1e-5)
+        got = ops.conv3x3_winograd(z, ops.winograd_filter(w, tile), K, in_stats=st, in_eps=1e-5)
         want = Fn.conv2d(torch.relu(Fn.instance_norm(z, eps=1e-5)), w, None, 1, 1)
-        assert (got - want).abs().max().item() < 3e-5 * max(1.0, want.abs().max().item())
+        assert (got - want).abs().max().item() < 1.5 * WINO_TOL[tile] * max(1.0, want.abs().max().item())
     # a residual block end to end, chained path against the stock operators
     from visual_odometry_amd.raft.layers import ResidualBlock, fused_passes
     torch.manual_seed(4)
     blk = ResidualBlock(64, 64, "instance").to(DEV).eval()
     x = torch.relu(_rand(2, 64, 37, 52, seed=97)).to(DEV)
-    with torch.no_grad():
-        a = blk(x)
-        with fused_passes():
-            b = blk(x)
-    assert (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
+    try:
+        layers.winograd_tile(tile)
+        with torch.no_grad():
+            a = blk(x)
+            with fused_passes():
+                b = blk(x)
+    finally:
+        layers.winograd_tile(0)
+    assert (a - b).abs().max().item() < (1e-4 if tile == 2 else 5e-4) * max(1.0, a.abs().max().item())
 
 
-def test_kernels_write_channel_slices_in_place(vo):
+@pytest.mark.parametrize("tile", [2, 4])
+def test_kernels_write_channel_slices_in_place(vo, tile):
     """Winograd convolution and bilinear resize writing straight into a channel slice of a
     wider tensor (the consumer's concatenated input): neighbours untouched, values equal."""
     import torch.nn.functional as Fn
@@ -558,10 +581,10 @@ def test_kernels_write_channel_slices_in_place(vo):
     x, w = _rand(N, C, H, W, seed=100).to(DEV), (_rand(K, C, 3, 3, seed=101) / 12).to(DEV)
     bias = _rand(K, seed=102).to(DEV)
     wide = torch.full((N, 7 + K + 5, H, W), 3.25, device=DEV)
-    got = ops.conv3x3_winograd(x, ops.winograd_filter(w), K, None, bias, True, out=wide[:, 7:7 + K])
+    got = ops.conv3x3_winograd(x, ops.winograd_filter(w, tile), K, None, bias, True, out=wide[:, 7:7 + K])
     want = torch.relu(Fn.conv2d(x, w, bias, 1, 1))
     assert got.data_ptr() == wide[:, 7:7 + K].data_ptr()
-    assert (wide[:, 7:7 + K] - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert (wide[:, 7:7 + K] - want).abs().max().item() < WINO_TOL[tile] * max(1.0, want.abs().max().item())
     assert torch.all(wide[:, :7] == 3.25) and torch.all(wide[:, 7 + K:] == 3.25)
     small = _rand(N, 6, 9, 12, seed=103).to(DEV)
     wide = torch.full((N, 10, H, W), -1.5, device=DEV)
@@ -572,4 +595,4 @@ def test_kernels_write_channel_slices_in_place(vo):
     with pytest.raises(ValueError):
         ops.resize_bilinear(small, (H, W), out=wide[:, 2:7])
     with pytest.raises(ValueError):
-        ops.conv3x3_winograd(x, ops.winograd_filter(w), K, out=wide.permute(0, 1, 3, 2)[:, :K])
+        ops.conv3x3_winograd(x, ops.winograd_filter(w, tile), K, out=wide.permute(0, 1, 3, 2)[:, :K])

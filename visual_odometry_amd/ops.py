@@ -204,15 +204,21 @@ def resize_bilinear(x: torch.Tensor, size, out: torch.Tensor | None = None) -> t
     return out
 
 
-def winograd_filter(weight: torch.Tensor) -> torch.Tensor:
-    """(K,C,3,3) float32 weight -> the transformed filter vo_conv3x3_winograd consumes."""
+def winograd_filter(weight: torch.Tensor, tile: int = 2) -> torch.Tensor:
+    """(K,C,3,3) float32 weight -> the transformed filter conv3x3_winograd consumes.
+    ``tile`` 2: F(2x2,3x3), 16 positions; 4: F(4x4,3x3), 36 positions (fewer multiplies,
+    rounding error about 1e-5 of the largest output instead of 5e-7)."""
     if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
         raise ValueError("weight must be (K,C,3,3)")
+    if tile not in (2, 4):
+        raise ValueError("tile must be 2 or 4")
     K, C = weight.shape[:2]
     if C % 8:
         raise ValueError("the Winograd path needs a multiple of 8 input channels")
-    out = torch.empty(((K + 63) // 64 * 64 * C * 16,), device=weight.device, dtype=torch.float32)
-    _call("vo_winograd_filter", _dev(weight.detach(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    positions = 16 if tile == 2 else 36
+    out = torch.empty(((K + 63) // 64 * 64 * C * positions,), device=weight.device, dtype=torch.float32)
+    _call("vo_winograd_filter" if tile == 2 else "vo_winograd4_filter", _dev(weight.detach(), "weight", torch.float32),
+          out.data_ptr(), K, C, _stream())
     return out
 
 
@@ -223,17 +229,23 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
                      in_eps: float = 1e-5) -> torch.Tensor:
     """x (N,C,H,W) float32, transformed filter of a (K,C,3,3) weight -> conv2d(x, weight, padding=1),
     optionally followed in the same kernel by *scale[k] + shift[k], ReLU and relu(. + skip).
+    The size of ``transformed`` tells which of the two kernels it was made for (winograd_filter's tile).
     ``out`` may be a channel slice of a wider NCHW tensor (dense (K,H,W) blocks, any batch stride).
     ``stats``: zeroed float64 (N,K,2) that receives each plane's sum and sum of squares of the
     raw output (for instance_norm_apply_; no epilogue in that case).
     ``in_stats``: such sums of the INPUT x (N,C,2): x is instance-normalised and ReLU-ed while it
     is loaded, so the tensor between two convolutions needs no normalisation pass of its own."""
     N, C, H, W = x.shape
-    if transformed.numel() != (K + 63) // 64 * 64 * C * 16:
+    per_position = (K + 63) // 64 * 64 * C
+    if transformed.numel() == per_position * 16:
+        name, tile, positions = "vo_conv3x3_winograd", 2, 16
+    elif transformed.numel() == per_position * 36:
+        name, tile, positions = "vo_conv3x3_winograd4", 4, 36
+    else:
         raise ValueError("transformed filter does not match (K, C)")
-    for t, name in ((scale, "scale"), (shift, "shift")):
+    for t, tname in ((scale, "scale"), (shift, "shift")):
         if t is not None and t.numel() != K:
-            raise ValueError(f"{name} must have one entry per output channel")
+            raise ValueError(f"{tname} must have one entry per output channel")
     if scale is not None and shift is None:
         raise ValueError("scale needs shift")
     if skip is not None and tuple(skip.shape) != (N, K, H, W):
@@ -248,12 +260,12 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
     if stats is not None:
         if stats.numel() != N * K * 2 or shift is not None or relu or skip is not None:
             raise ValueError("stats must be (N,K,2) float64 and excludes the epilogue")
-    _call("vo_conv3x3_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), py, sy,
+    _call(name, _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), py, sy,
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
           _opt(skip, "skip", torch.float32), _opt(stats, "stats", torch.float64),
           _opt(in_stats, "in_stats", torch.float64), float(in_eps), N, C, H, W, K, _stream(),
           nbytes=4 * (x.numel() + out.numel() * (1 + (skip is not None))),
-          flops=2 * 16 * C * K * N * ((H + 1) // 2) * ((W + 1) // 2))       # transformed-domain multiply-adds
+          flops=2 * positions * C * K * N * ((H + tile - 1) // tile) * ((W + tile - 1) // tile))   # transformed-domain multiply-adds
     return out
 
 

@@ -84,32 +84,53 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
-_WINOGRAD = True            # float32 3x3 stride-1 convolutions on the hand-written Winograd/MFMA kernel
+_WINOGRAD = True            # float32 3x3 stride-1 convolutions on the hand-written Winograd/MFMA kernels
+_WINOGRAD_TILE = 0          # 0: pick F(2x2,3x3) or F(4x4,3x3) per layer shape; 2 or 4: force one
 
 
 def winograd_enabled(on: bool) -> None:
-    """Switch the hand-written 3x3 kernel on or off (off: every convolution goes to MIOpen)."""
+    """Switch the hand-written 3x3 kernels on or off (off: every convolution goes to MIOpen)."""
     global _WINOGRAD
     _WINOGRAD = bool(on)
 
 
+def winograd_tile(tile: int) -> None:
+    """Force the output tile of the Winograd kernels (2 or 4), or 0 for the per-shape choice."""
+    global _WINOGRAD_TILE
+    if tile not in (0, 2, 4):
+        raise ValueError("tile must be 0, 2 or 4")
+    _WINOGRAD_TILE = tile
+
+
+def _winograd_tile_for(H: int, W: int) -> int:
+    """F(4x4,3x3) does a pixel in about 1/1.55 of F(2x2,3x3)'s time but works on 16x32-pixel
+    blocks instead of 16x16: take it unless the padding of narrow maps eats the gain."""
+    if _WINOGRAD_TILE:
+        return _WINOGRAD_TILE
+    return 4 if ((W + 31) // 32) * 2 < 1.55 * ((W + 15) // 16) else 2
+
+
 def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
-    """The cached transformed filter when this convolution can run on the Winograd F(2x2,3x3)
-    matrix-core kernel (3x3 / stride 1 / padding 1, float32, >= 32 output channels, input
-    channels a multiple of 8), else None."""
+    """The cached transformed filter when this convolution can run on a Winograd matrix-core
+    kernel (3x3 / stride 1 / padding 1, float32, >= 32 output channels, input channels a
+    multiple of 8), else None."""
     if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] % 8 == 0 and weight.shape[0] >= 32
             and weight.shape[1] == x.shape[1]):
         return None
-    # the transformed filter rides on the weight tensor object itself (an address-keyed
-    # table would hand a new model the filters of a freed one)
+    # the transformed filters ride on the weight tensor object itself (an address-keyed
+    # table would hand a new model the filters of a freed one), one per kernel variant
+    tile = _winograd_tile_for(x.shape[2], x.shape[3])
     key = (weight._version, weight.data_ptr())
-    cached = getattr(weight, "_vo_winograd", None)
-    if cached is None or cached[0] != key:
-        cached = (key, ops.winograd_filter(weight.contiguous()))
-        weight._vo_winograd = cached
-    return cached[1]
+    table = getattr(weight, "_vo_winograd", None)
+    if table is None or table[0] != key:
+        table = (key, {})
+        weight._vo_winograd = table
+    U = table[1].get(tile)
+    if U is None:
+        U = table[1][tile] = ops.winograd_filter(weight.contiguous(), tile)
+    return U
 
 
 def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
