@@ -34,7 +34,10 @@ constexpr int RAW_PER_LANE = (RAW_FLOATS + NT - 1) / NT;     // 7
 constexpr int V_XI = CB * 32;              // floats per position: [kk][tile][ks], c = 2*ks + kk
 constexpr int V_FLOATS = 36 * V_XI;        // 9216
 constexpr int A_CHUNK = 36 * 2 * 64 * 4;   // floats of transformed filter per (channel block, chunk)
+constexpr int M_FLOATS = 36 * 32 * 16;     // one round of the output transform: [xi][tile][channel]
+constexpr int LDS_FLOATS = 2 * M_FLOATS > 2 * V_FLOATS + 2 * RAW_FLOATS ? 2 * M_FLOATS : 2 * V_FLOATS + 2 * RAW_FLOATS;
 constexpr int MAX_NORM_C = 512;
+constexpr int RING = 3;                    // filter-fragment loads in flight per wave
 
 // U = G g G^T for every (k, c), in the register order of the MFMA A operand:
 //   Ug[kb][chunk][xi][kt][lane][ks]:  k = kb*64 + kt*32 + (lane & 31),  c = chunk*8 + 2*ks + (lane >> 5)
@@ -102,16 +105,18 @@ __device__ __forceinline__ void out_1d(float m0, float m1, float m2, float m3, f
     o[3] = fmaf(8.0f, s, q) + m5;
 }
 
-template <bool NORM_IN>
+// HALF: the launch covers one block of output channels of which only the lower 32 exist (K mod 64
+// in 1..32): the upper k-tile's matrix instructions, filter loads and output rounds are left out.
+template <bool NORM_IN, bool HALF>
 __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                    float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H, int W,
-                                                   int K, int blocks_x, int blocks_y, int kblocks) {
-    // V and the raw patch are double-buffered; after the loop the front of the array holds M
-    // (36 positions x 16 channels x 32 tiles) for the output transform.
-    __shared__ __align__(16) float lds[2 * V_FLOATS + 2 * RAW_FLOATS + (NORM_IN ? 2 * MAX_NORM_C : 0)];
+                                                   int K, int blocks_x, int blocks_y, int kblocks, int kb_base) {
+    // V and the raw patch are double-buffered; after the loop the array holds two buffers of M
+    // (36 positions x 32 tiles x 16 channels) for the output transform.
+    __shared__ __align__(16) float lds[LDS_FLOATS + (NORM_IN ? 2 * MAX_NORM_C : 0)];
     float* Vs = lds;
     float* raw = lds + 2 * V_FLOATS;
-    float2* nrm = reinterpret_cast<float2*>(lds + 2 * V_FLOATS + 2 * RAW_FLOATS);
+    float2* nrm = reinterpret_cast<float2*>(lds + LDS_FLOATS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
         const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
         bid = (int)(((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3));
     }
-    const int kb = bid % kblocks; bid /= kblocks;
+    const int kb = kb_base + bid % kblocks; bid /= kblocks;
     const int bx = bid % blocks_x; bid /= blocks_x;
     const int by = bid % blocks_y;
     const int n = bid / blocks_y;
@@ -178,9 +183,10 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
         }
     };
 
-    // filter fragments: a ring of three 16-byte loads, (position, k-tile) step s of a chunk in slot s % 3
+    // filter fragments: the six 16-byte loads of a chunk ((position, k-tile) step s in slot s); a slot
+    // is refilled for the next chunk as soon as its matrix instructions have been issued
     const int a_off = (3 * wave * 2 * 64 + lane) * 16;           // + step * 1024 + chunk * A_CHUNK * 4 bytes
-    u32x4 ar[3];
+    u32x4 ar[RING];
     auto load_a = [&](int chunk, int step, int slot) {
         chunk = chunk < nchunks ? chunk : nchunks - 1;
         ar[slot] = __builtin_amdgcn_raw_buffer_load_b128(urs, a_off + step * 1024, chunk * (A_CHUNK * 4), 0);
@@ -229,28 +235,36 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
         else if (tg == 1) transform_g(buf, std::integral_constant<int, 1>{});
         else transform_g(buf, std::integral_constant<int, 2>{});
     };
-    // multiply: positions 3*wave + xl; B fragment of a position = one 16-byte read (four k-steps)
-    auto multiply = [&](int buf, int chunk) {
-        const float* vb = Vs + buf * V_FLOATS + (3 * wave) * V_XI + lane * 4;
+    // multiply: positions 3*wave + xl; the B fragment of a position is one 16-byte read (four k-steps)
+    auto multiply_xl = [&](int buf, int chunk, auto xtag) {
+        constexpr int xl = decltype(xtag)::value;
+        const float4 b = *reinterpret_cast<const float4*>(Vs + buf * V_FLOATS + (3 * wave + xl) * V_XI + lane * 4);
+        const float bs[4] = {b.x, b.y, b.z, b.w};
+        constexpr int s0 = HALF ? xl : (xl * 2) % RING, s1 = (xl * 2 + 1) % RING;
+        // consecutive matrix instructions alternate between the two k-tiles' accumulators
 #pragma unroll
-        for (int xl = 0; xl < 3; ++xl) {
-            const float4 b = *reinterpret_cast<const float4*>(vb + xl * V_XI);
-            const float bs[4] = {b.x, b.y, b.z, b.w};
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[xl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(ar[s0][ks]), bs[ks], acc[xl][0], 0, 0, 0);
+            if (!HALF) acc[xl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(ar[s1][ks]), bs[ks], acc[xl][1], 0, 0, 0);
+        }
+        if (HALF) {                                              // three fragments per chunk: a full chunk of lookahead
+            load_a(chunk + 1, 2 * xl, xl);
+        } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const int step = xl * 2 + kt, slot = step % 3;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    acc[xl][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(ar[slot][ks]), bs[ks], acc[xl][kt], 0, 0, 0);
-                if (step < 3) load_a(chunk, step + 3, slot);     // second half of this chunk
-                else load_a(chunk + 1, step - 3, slot);          // first half of the next
+                const int step = xl * 2 + kt;
+                if (step + RING < 6) load_a(chunk, step + RING, step % RING);
+                else load_a(chunk + 1, step + RING - 6, step % RING);
             }
         }
     };
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
+    using X2 = std::integral_constant<int, 2>;
 
     load_raw(0);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) load_a(0, s, s);
+    for (int s = 0; s < RING; ++s) load_a(0, HALF ? 2 * s : s, s);
     store_raw(0, 0);
     load_raw(1);
     __syncthreads();
@@ -262,34 +276,46 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
         const int cur = chunk & 1;
         // V[cur] is complete, raw[cur ^ 1] holds chunk + 1, the registers hold chunk + 2
         if (chunk + 1 < nchunks) transform(cur ^ 1);
-        multiply(cur, chunk);
+        multiply_xl(cur, chunk, X0{}); multiply_xl(cur, chunk, X1{}); multiply_xl(cur, chunk, X2{});
         store_raw(cur, chunk + 2);                               // raw[cur] was consumed one iteration ago
         load_raw(chunk + 3);
         __syncthreads();
     }
 
-    // output transform, 16 output channels per round: M[xi][row][tile] through LDS.  The row a
-    // channel is stored in interleaves the two lane halves so that a wave's store has no bank conflict.
+    // Output transform, 16 output channels per round, M[xi][tile][channel] through LDS.  A lane's
+    // four accumulator elements e..e+3 are four consecutive channels: one 16-byte store, its slot
+    // inside the tile's 16 channels XOR-swizzled with the tile index so that neither these stores
+    // nor the scalar reads below collide on banks.  M is double-buffered: the stores of round
+    // q+1 go out while round q is transformed, one barrier per round.
     float* yn = y + (int64_t)n * ep.y_batch_stride;
-    const bool quad_store = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ep.y_batch_stride & 3) == 0;
+    const bool quad_store = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ep.y_batch_stride & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(ep.skip) & 15) == 0;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yn, 0, K * H * W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ep.skip ? ep.skip + (int64_t)n * K * H * W : x), 0, ep.skip ? K * H * W * 4 : 0, 0x00020000);
     const int kk = lane >> 5, nn = lane & 31;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (q) __syncthreads();
+    auto put_m = [&](int q) {
+        float* mb = lds + (q & 1) * M_FLOATS + (3 * wave) * 512 + nn * 16;
 #pragma unroll
         for (int xl = 0; xl < 3; ++xl)
 #pragma unroll
-            for (int eh = 0; eh < 8; ++eh) {
-                const int e = (q & 1) * 8 + eh;
-                const int row = kk + 2 * (e & 3) + 8 * ((e >> 2) & 1);
-                lds[(3 * wave + xl) * 512 + row * 32 + nn] = acc[xl][q >> 1][e];
+            for (int eh = 0; eh < 2; ++eh) {
+                const int e = (q & 1) * 8 + eh * 4;
+                const int g = 2 * eh + kk;                       // channels 4g..4g+3 of the round
+                const f32x16& a = acc[xl][q >> 1];
+                *reinterpret_cast<float4*>(mb + xl * 512 + 4 * (g ^ ((nn >> 2) & 3))) = make_float4(a[e], a[e + 1], a[e + 2], a[e + 3]);
             }
-        __syncthreads();
+    };
+    constexpr int rounds = HALF ? 2 : 4;
+    put_m(0);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < rounds; ++q) {
+        if (q + 1 < rounds) put_m(q + 1);
         if (tid < 512) {
-            const int tile = tid & 31, row = tid >> 5;
-            const int kq = ((row >> 1) & 3) + 4 * (row & 1) + 8 * (row >> 3);
+            const int tile = tid & 31, kq = tid >> 5;
             const int k = kb * KB + q * 16 + kq;
-            const float* mp = lds + row * 32 + tile;
+            const float* mp = lds + (q & 1) * M_FLOATS + tile * 16 + 4 * ((kq >> 2) ^ ((tile >> 2) & 3)) + (kq & 3);
             float s[6][4];                                       // A^T m, column by column
 #pragma unroll
             for (int b = 0; b < 6; ++b)
@@ -314,7 +340,39 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
                     atomicAdd(st + 1, (double)pq);
                 }
             }
-            if (k < K && oy < H && ox < W) {
+            if (quad_store && k < K && oy + 3 < H && ox < W) {
+                // whole tile inside the image, rows 16-byte aligned: straight-line code, 16-byte accesses
+                const int voff = ((k * H + oy) * W + ox) * 4;
+                if (ep.shift) {
+                    const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift[k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[r][c] = fmaf(o[r][c], sc, sh);
+                }
+                if (ep.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[r][c] = fmaxf(o[r][c], 0.0f);
+                }
+                if (ep.skip) {
+                    u32x4 sk[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sk[r] = __builtin_amdgcn_raw_buffer_load_b128(srs, voff + r * W * 4, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[r][c] = fmaxf(o[r][c] + __uint_as_float(sk[r][c]), 0.0f);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = __float_as_uint(o[r][c]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, yrs, voff + r * W * 4, 0, 0);
+                }
+            } else if (k < K && oy < H && ox < W) {
                 const int64_t off = ((int64_t)k * H + oy) * W + ox;
                 float* p = yn + off;
                 if (ep.shift) {
@@ -330,29 +388,21 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[r][c] = fmaxf(o[r][c], 0.0f);
                 }
-                if (ep.skip) {
-                    const float* sp = ep.skip + (int64_t)n * K * H * W + off;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (oy + r >= H) break;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (ox + c < W) o[r][c] = fmaxf(o[r][c] + sp[(int64_t)r * W + c], 0.0f);
-                    }
-                }
+                const float* sp = ep.skip ? ep.skip + (int64_t)n * K * H * W + off : nullptr;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (oy + r >= H) break;
-                    if (quad_store) {
-                        *reinterpret_cast<float4*>(p + (int64_t)r * W) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
-                    } else {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (ox + c < W) p[(int64_t)r * W + c] = o[r][c];
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (ox + c < W) {
+                            float v = o[r][c];
+                            if (sp) v = fmaxf(v + sp[(int64_t)r * W + c], 0.0f);
+                            p[(int64_t)r * W + c] = v;
+                        }
                 }
             }
         }
+        if (q + 1 < rounds) __syncthreads();
     }
 }
 
@@ -381,22 +431,30 @@ extern "C" int vo_conv3x3_winograd4(const float* x, const float* transformed, fl
     if (y_batch_stride == 0) y_batch_stride = (int64_t)K * H * W;
     VO_REQUIRE(y_batch_stride >= (int64_t)K * H * W, "vo_conv3x3_winograd4: y_batch_stride smaller than one item");
     if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: C=%d is not a multiple of %d", C, CB);
-    if ((int64_t)C * H * W * 4 >= 0x7fffffffLL)
-        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: one image of the input exceeds 2 GiB");
+    if ((int64_t)C * H * W * 4 >= 0x7fffffffLL || (int64_t)K * H * W * 4 >= 0x7fffffffLL)
+        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: one image of the input or output exceeds 2 GiB");
     if (in_stats && C > MAX_NORM_C)
         return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: normalise-on-load supports at most %d input channels", MAX_NORM_C);
     const int bx = (W + 31) / 32, by = (H + 15) / 16;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: grid too large");
-    const dim3 grid((unsigned)(blocks * kblocks));
     const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats};
-    if (in_stats)
-        wino4_kernel<true><<<grid, dim3(NT), 0, vo_stream(stream)>>>(x, transformed, y, ep, InputNorm{in_stats, in_eps}, C, H, W,
-                                                                     K, bx, by, kblocks);
-    else
-        wino4_kernel<false><<<grid, dim3(NT), 0, vo_stream(stream)>>>(x, transformed, y, ep, InputNorm{nullptr, 0.0f}, C, H, W,
-                                                                      K, bx, by, kblocks);
+    const InputNorm nrm{in_stats, in_eps};
+    // a last block with at most 32 channels goes out as a launch of its own that skips the empty k-tile
+    const int rem = K % KB;
+    const int full = (rem >= 1 && rem <= 32) ? kblocks - 1 : kblocks;
+    hipStream_t st = vo_stream(stream);
+    if (full > 0) {
+        const dim3 grid((unsigned)(blocks * full));
+        if (in_stats) wino4_kernel<true, false><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, full, 0);
+        else wino4_kernel<false, false><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, full, 0);
+    }
+    if (full < kblocks) {
+        const dim3 grid((unsigned)blocks);
+        if (in_stats) wino4_kernel<true, true><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, 1, full);
+        else wino4_kernel<false, true><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, 1, full);
+    }
     VO_CHECK_LAUNCH("vo_conv3x3_winograd4");
     return VO_OK;
 }
