@@ -139,6 +139,17 @@ int vo_conv3x3_winograd4(const float* x, const float* transformed, float* y, int
                          double* stats, const double* in_stats, float in_eps,
                          int N, int C, int H, int W, int K, void* stream);
 
+/* 1x5 (padding (0,2)) and 5x1 (padding (2,0)) stride-1 float32 convolutions, NCHW, no bias, as
+ * one-dimensional Winograd F(4,5) on the matrix cores: the gate convolutions of the separable
+ * GRU in RAFT's update block (model built at flow/flow_map_RAFT.py:42).
+ *   vo_winograd1d_filter  weight (K,C,5) (the (K,C,1,5) or (K,C,5,1) tensor, contiguous) ->
+ *                         transformed filter, ceil(K/64)*64 * C * 8 floats.  C multiple of 8.
+ *   vo_conv5_winograd     x (N,C,H,W), transformed filter -> y (N,K,H,W); vertical = 0: the
+ *                         filter runs along W (1x5), 1: along H (5x1).  y must not alias x. */
+int vo_winograd1d_filter(const float* weight, float* transformed, int K, int C, void* stream);
+int vo_conv5_winograd(const float* x, const float* transformed, float* y, int N, int C, int H, int W, int K,
+                      int vertical, void* stream);
+
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one
  * plane per filter tap, planes (N, K*9, H, W) in (k, r, s) order; this pass adds the nine

@@ -596,3 +596,42 @@ def test_kernels_write_channel_slices_in_place(vo, tile):
         ops.resize_bilinear(small, (H, W), out=wide[:, 2:7])
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(x, ops.winograd_filter(w, tile), K, out=wide.permute(0, 1, 3, 2)[:, :K])
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 8, 5, 7, 64), (2, 16, 33, 21, 40), (2, 64, 60, 80, 126), (1, 24, 1, 1, 33),
+                                       (2, 384, 30, 40, 256), (1, 8, 70, 3, 32)])
+@pytest.mark.parametrize("vertical", [False, True])
+def test_winograd_conv5_matches_direct_convolution(vo, N, C, H, W, K, vertical):
+    """The one-dimensional F(4,5) Winograd/MFMA kernel (1x5 and 5x1 GRU gate convolutions) against
+    the float64 direct convolution: ragged sizes, partial channel blocks, run-to-run identical.
+    Tolerance 2e-5 of the largest output (measured 4e-6; MIOpen's float32 result is at 2e-6)."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=110).to(DEV)
+    shape = (K, C, 5, 1) if vertical else (K, C, 1, 5)
+    w = (_rand(*shape, seed=111) / (5 * C) ** 0.5).to(DEV)
+    U = ops.winograd1d_filter(w)
+    got = ops.conv5_winograd(x, U, K, vertical)
+    want = Fn.conv2d(x.double(), w.double(), None, 1, (2, 0) if vertical else (0, 2))
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.equal(got, ops.conv5_winograd(x, U, K, vertical))
+    with pytest.raises(ValueError):
+        ops.winograd1d_filter(_rand(8, 6, 1, 5, seed=1).to(DEV))
+    with pytest.raises(ValueError):
+        ops.conv5_winograd(x, U[:-1].contiguous(), K, vertical)
+
+
+def test_separable_gru_on_the_winograd_kernel(vo):
+    """SepConvGRU (RAFT-Flow's update block) through the fused path, whose 1x5 / 5x1 gate
+    convolutions run on the F(4,5) kernel, against the stock operators."""
+    from visual_odometry_amd.raft.layers import fused_passes
+    from visual_odometry_amd.raft.update import SepConvGRU
+    torch.manual_seed(5)
+    gru = SepConvGRU(128, 256).to(DEV).eval()
+    h, xin = torch.tanh(_rand(2, 128, 30, 40, seed=120)).to(DEV), _rand(2, 256, 30, 40, seed=121).to(DEV)
+    with torch.no_grad():
+        a = gru(h, xin)
+        with fused_passes():
+            b = gru(h, xin)
+    assert (a - b).abs().max().item() < 2e-5

@@ -269,6 +269,31 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
     return out
 
 
+def winograd1d_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,1,5) or (K,C,5,1) float32 weight -> the transformed filter conv5_winograd consumes."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) not in ((1, 5), (5, 1)):
+        raise ValueError("weight must be (K,C,1,5) or (K,C,5,1)")
+    K, C = weight.shape[:2]
+    if C % 8:
+        raise ValueError("the Winograd path needs a multiple of 8 input channels")
+    out = torch.empty(((K + 63) // 64 * 64 * C * 8,), device=weight.device, dtype=torch.float32)
+    _call("vo_winograd1d_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    return out
+
+
+def conv5_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, vertical: bool) -> torch.Tensor:
+    """x (N,C,H,W) float32, transformed filter of a (K,C,1,5) [vertical False] or (K,C,5,1) [True]
+    weight -> the stride-1 "same" convolution conv2d(x, weight, padding=(0,2) / (2,0))."""
+    N, C, H, W = x.shape
+    if transformed.numel() != (K + 63) // 64 * 64 * C * 8:
+        raise ValueError("transformed filter does not match (K, C)")
+    out = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    _call("vo_conv5_winograd", _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), out.data_ptr(),
+          N, C, H, W, K, int(bool(vertical)), _stream(), nbytes=4 * (x.numel() + out.numel()),
+          flops=2 * 8 * C * K * N * (H * ((W + 3) // 4) if not vertical else ((H + 3) // 4) * W))   # transformed-domain multiply-adds
+    return out
+
+
 def shift_add_3x3(planes: torch.Tensor, bias: torch.Tensor | None, K: int) -> torch.Tensor:
     """planes (N, K*9, H, W): per-tap 1x1 products in (k, r, s) order -> the 3x3 / padding 1
     convolution output (N, K, H, W) (+ bias)."""

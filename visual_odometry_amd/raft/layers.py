@@ -140,6 +140,18 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     U = _winograd_filter_for(x, weight, stride, padding, dilation, groups)
     if U is not None:
         return ops.conv3x3_winograd(x, U, weight.shape[0])
+    ks = tuple(weight.shape[2:])
+    if (_WINOGRAD and ks in ((1, 5), (5, 1)) and tuple(padding) == (ks[0] // 2, ks[1] // 2) and tuple(stride) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.is_cuda and x.is_contiguous() and weight.shape[1] % 8 == 0 and weight.shape[0] >= 32
+            and weight.shape[1] == x.shape[1]):
+        # the separable GRU's gate convolutions: one-dimensional Winograd F(4,5) on the matrix cores
+        key = (weight._version, weight.data_ptr())
+        cached = getattr(weight, "_vo_winograd1d", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.winograd1d_filter(weight))
+            weight._vo_winograd1d = cached
+        return ops.conv5_winograd(x, cached[1], weight.shape[0], ks == (5, 1))
     return F.conv2d(x, weight, None, stride, padding, dilation, groups)
 
 
