@@ -67,7 +67,7 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
 
 PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_corr_pyramid_2d": "pyr2d",
             "vo_corr_pyramid_1d": "pyr1d", "vo_corr_lookup_2d": "lookup2d", "vo_corr_lookup_1d": "lookup1d",
-            "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4"}
+            "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4", "vo_conv5_winograd": "winograd1d"}
 
 
 def pmc_traffic(kernel: str, B: int, H: int, W: int):

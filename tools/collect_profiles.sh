@@ -15,13 +15,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_${c}_corr -- python3 $R/tools/profile_kernels.py --batch $B --reps 3 --only corr2d,pyr2d,lookup2d,lookup1d,corr1d,pyr1d > $R/gpurun_out/pmc_${c}_corr.log 2>&1
   echo "$c corr done"
 done
-# the Winograd convolution: traffic as the mean over all its launches of a bench step, MFMA
-# busy cycles at two layer shapes
-cd $R && bash tools/pmc_bench_kernel.sh wino_kernel wino && cd /tmp
-for shape in "16 64 480 640 64" "16 256 120 160 128"; do
+# the Winograd convolutions: traffic as the mean over all their launches of a bench step, MFMA
+# busy cycles at two 3x3 layer shapes and one GRU gate convolution
+cd $R && bash tools/pmc_bench_kernel.sh "wino4_kernel wino1d_kernel" wino && cd /tmp
+PMCW="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+for shape in "16 64 480 640 64" "16 256 120 160 128" "32 384 60 80 256 3 5"; do
   tag=$(echo $shape | tr ' ' '_')
-  timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_w1_$tag -- python3 $R/tools/wino_one.py $shape > $R/gpurun_out/pmc_w1.log 2>&1
-  python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_w1_$tag wino_kernel > $R/gpurun_out/pmc_w1_$tag.json
+  timeout -s KILL 120 rocprofv3 --pmc $PMCW --output-format csv -d $R/gpurun_out/pmc_w1_$tag -- python3 $R/tools/wino_one.py $shape > $R/gpurun_out/pmc_w1.log 2>&1
+  python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_w1_$tag wino4_kernel wino1d_kernel > $R/gpurun_out/pmc_w1_$tag.json
   rm -rf $R/gpurun_out/pmc_w1_$tag
 done
 echo "winograd done"

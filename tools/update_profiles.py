@@ -29,26 +29,29 @@ w = counter("pmc_WRITE_SIZE_encoders.json", "instnorm_kernel|WRITE_SIZE")
 traffic["kernels"]["instnorm"] = {"FETCH_SIZE_KiB_per_launch": f["mean_per_launch"], "launches_fetch": f["launches"],
                                   "WRITE_SIZE_KiB_per_launch": w["mean_per_launch"], "launches_write": w["launches"],
                                   "note": "mean over the launches of the feature encoders of both networks"}
-f = counter("pmc_wino_FETCH_SIZE.json", "wino_kernel|FETCH_SIZE")
-w = counter("pmc_wino_WRITE_SIZE.json", "wino_kernel|WRITE_SIZE")
-traffic["kernels"]["winograd"] = {"FETCH_SIZE_KiB_per_launch": f["mean_per_launch"], "launches_fetch": f["launches"],
-                                  "WRITE_SIZE_KiB_per_launch": w["mean_per_launch"], "launches_write": w["launches"],
-                                  "note": "mean over every launch of a short bench run (all 3x3 layer shapes of both networks)"}
+for key, kern in (("winograd4", "wino4_kernel"), ("winograd1d", "wino1d_kernel")):
+    f = counter("pmc_wino_FETCH_SIZE.json", kern + "|FETCH_SIZE")
+    w = counter("pmc_wino_WRITE_SIZE.json", kern + "|WRITE_SIZE")
+    traffic["kernels"][key] = {"FETCH_SIZE_KiB_per_launch": f["mean_per_launch"], "launches_fetch": f["launches"],
+                               "WRITE_SIZE_KiB_per_launch": w["mean_per_launch"], "launches_write": w["launches"],
+                               "note": "mean over every launch of a short bench run (all layer shapes of both networks)"}
 json.dump(traffic, open(P(f"{tag}_pmc_traffic.json"), "w"), indent=1)
 json.dump(traffic, open(P("pmc_traffic.json"), "w"), indent=1)
 
 util_path = P(f"{tag}_mfma_util.json")
 util = json.load(open(util_path)) if os.path.exists(util_path) else {"kernels": {}}
-for shape in ("16_64_480_640_64", "16_256_120_160_128"):
+for shape, kern in (("16_64_480_640_64", "wino4_kernel"), ("16_256_120_160_128", "wino4_kernel"),
+                    ("32_384_60_80_256_3_5", "wino1d_kernel")):
     d = json.load(open(G(f"pmc_w1_{shape}.json")))
-    c = {k.split("|")[1]: v["mean_per_launch"] for k, v in d.items()}
+    c = {k.split("|")[1]: v["mean_per_launch"] for k, v in d.items() if k.startswith(kern)}
     c["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8)
-    util["kernels"][f"wino_kernel N,C,H,W,K = {shape.replace('_', ',')}"] = c
-util["note_winograd"] = ("same counters over tools/wino_one.py; mfma_util = MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8 XCDs)")
+    util["kernels"][f"{kern} N,C,H,W,K = {','.join(shape.split('_')[:5])}"] = c
+util["note_winograd"] = ("same counters over tools/wino_one.py; mfma_util = MFMA busy cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8 XCDs); "
+                         "wino_kernel rows are the F(2x2,3x3) kernel, wino4_kernel F(4x4,3x3), wino1d_kernel F(4,5)")
 json.dump(util, open(util_path, "w"), indent=1)
 
 shutil.copy(G("step_breakdown.txt"), P(f"{tag}_steady_state_step_breakdown.txt"))
 shutil.copy(G("bench_kernel_stats_top45.csv"), P(f"{tag}_bench_kernel_stats_top45.csv"))
 print(json.dumps({k: v["mfma_util"] for k, v in util["kernels"].items() if "wino" in k}, indent=1))
-t = traffic["kernels"]["winograd"]
+t = traffic["kernels"]["winograd4"]
 print("winograd bytes/launch (2xFETCH + WRITE):", (2 * t["FETCH_SIZE_KiB_per_launch"] + t["WRITE_SIZE_KiB_per_launch"]) * 1024 / 1e6, "MB")
