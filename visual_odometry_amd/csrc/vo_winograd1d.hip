@@ -10,9 +10,10 @@
 //             [0 -2 4 5/2 -5 -1/2 1 0], [0 -1 0 21/4 0 -21/4 0 1]
 //   A^T rows: [1 1 1 1 1 1 1 0], [0 1 -1 2 -2 1/2 -1/2 0], [0 1 1 4 4 1/4 1/4 0], [0 1 -1 8 -8 1/8 -1/8 1]
 // (one-dimensional transforms: the float32 rounding error stays within a few times that of the
-// direct sum).  One workgroup of 8 waves owns a 32x16-pixel block (128 tiles of four pixels along
-// the filter's axis) and 64 output channels; wave w owns position w: 2 k-tiles x 4 tile groups =
-// 128 accumulator registers, one pair of 16-byte filter loads per chunk of 8 input channels.
+// direct sum).  One workgroup of 8 waves owns a 16x16-pixel block (64 tiles of four pixels along
+// the filter's axis; 32x16 as a template option) and 64 output channels; wave w owns position w:
+// 2 k-tiles x 2 tile groups = 64 accumulator registers, one pair of 16-byte filter loads per chunk
+// of 8 input channels.
 #include "vo_common.h"
 
 namespace {
@@ -23,14 +24,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CB = 8;                      // input channels per chunk
 constexpr int KB = 64;                     // output channels per workgroup
 constexpr int NT = 512;                    // threads per workgroup
-constexpr int TILES = 128;                 // tiles per workgroup
-constexpr int V_XI = CB * TILES;           // floats per position: [kk][tile][ks], c = 2*ks + kk
-constexpr int V_FLOATS = 8 * V_XI;         // 8192
-constexpr int RAW_MAX = CB * 32 * 20;      // raw patch of a chunk: 32x20 (along W) or 36x16 (along H) per channel
-constexpr int RAW_PER_LANE = RAW_MAX / NT; // 10
 constexpr int A_CHUNK = 8 * 2 * 64 * 4;    // floats of transformed filter per (channel block, chunk)
-constexpr int M_FLOATS = 8 * TILES * 16;   // one round of the output transform: [xi][tile][channel]
-constexpr int LDS_FLOATS = 2 * M_FLOATS > 2 * V_FLOATS + 2 * RAW_MAX ? 2 * M_FLOATS : 2 * V_FLOATS + 2 * RAW_MAX;
 
 // U = G g for every (k, c), in the register order of the MFMA A operand:
 //   Ug[kb][chunk][xi][kt][lane][ks]:  k = kb*64 + kt*32 + (lane & 31),  c = chunk*8 + 2*ks + (lane >> 5)
@@ -83,12 +77,22 @@ __device__ __forceinline__ void out_1d(const float* m, float* o) {
 }
 
 // DIR 0: filter along W (1x5, padding (0,2)); DIR 1: filter along H (5x1, padding (2,0)).
-template <int DIR>
-__global__ __launch_bounds__(NT) void wino1d_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
-                                                    float* __restrict__ y, int C, int H, int W, int K, int blocks_x,
-                                                    int blocks_y, int kblocks) {
-    constexpr int PR = DIR == 0 ? 32 : 36, PC = DIR == 0 ? 20 : 16;    // raw patch rows, columns
+// NTG: groups of 32 tiles per workgroup.  4: a 32x16-pixel block, 128 accumulator registers, one
+// workgroup per CU.  2: a 16x16-pixel block, 64 accumulator registers, at most 128 registers and
+// 64 KB of LDS, so two workgroups share a CU and the matrix pipe is fed by one while the other
+// sits in its per-chunk barrier / LDS round trip.
+template <int DIR, int NTG>
+__global__ __launch_bounds__(NT, NTG == 2 ? 4 : 2) void wino1d_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
+                                                                      float* __restrict__ y, int C, int H, int W, int K,
+                                                                      int blocks_x, int blocks_y, int kblocks) {
+    constexpr int TILES = 32 * NTG, ROWS = 8 * NTG;              // tiles and pixel rows per workgroup (16 columns)
+    constexpr int V_XI = CB * TILES, V_FLOATS = 8 * V_XI;        // per position: [kk][tile][ks], c = 2*ks + kk
+    constexpr int PR = DIR == 0 ? ROWS : ROWS + 4, PC = DIR == 0 ? 20 : 16;    // raw patch rows, columns
     constexpr int RAW_C = PR * PC, RAW_FLOATS = CB * RAW_C;
+    constexpr int RAW_MAX = CB * ROWS * 20;                      // the larger of the two patch shapes
+    constexpr int RAW_PER_LANE = RAW_MAX / NT;
+    constexpr int M_FLOATS = 8 * TILES * 16;                     // one round of the output transform: [xi][tile][channel]
+    constexpr int LDS_FLOATS = 2 * M_FLOATS > 2 * V_FLOATS + 2 * RAW_MAX ? 2 * M_FLOATS : 2 * V_FLOATS + 2 * RAW_MAX;
     __shared__ __align__(16) float lds[LDS_FLOATS];
     float* Vs = lds;
     float* raw = lds + 2 * V_FLOATS;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(NT) void wino1d_kernel(const float* __restrict__ x,
     const int by = bid % blocks_y;
     const int n = bid / blocks_y;
     const int nchunks = C / CB;
-    const int y0 = by * 32 - (DIR == 1 ? 2 : 0), x0 = bx * 16 - (DIR == 0 ? 2 : 0);
+    const int y0 = by * ROWS - (DIR == 1 ? 2 : 0), x0 = bx * 16 - (DIR == 0 ? 2 : 0);
     const float* xn = x + (int64_t)n * C * H * W;
 
     // Lanes of the zero padding carry an offset past the extent: a buffer load returns 0.0f there.
@@ -146,20 +150,20 @@ __global__ __launch_bounds__(NT) void wino1d_kernel(const float* __restrict__ x,
             a_nxt[kt] = __builtin_amdgcn_raw_buffer_load_b128(urs, a_off + kt * 1024, chunk * (A_CHUNK * 4), 0);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NTG];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NTG; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][j][e] = 0.0f;
 
-    // transform role, two (channel, tile) per lane and chunk: pass p of wave w takes kk = (2w+p) & 1
-    // and the 16 tiles of group (2w+p) >> 1; lane: ks = lane & 3, tile = 16*group + (lane >> 2)
+    // transform role, NTG/2 (channel, tile) per lane and chunk: pass p of wave w takes combination
+    // m = w*NTG/2 + p: kk = m & 1 and the 16 tiles of group m >> 1; lane: ks = lane & 3, tile = 16*group + (lane >> 2)
     auto transform = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int combo = 2 * wave + p, t_kk = combo & 1, tile = (combo >> 1) * 16 + (lane >> 2);
+        for (int p = 0; p < NTG / 2; ++p) {
+            const int combo = (NTG / 2) * wave + p, t_kk = combo & 1, tile = (combo >> 1) * 16 + (lane >> 2);
             const int c = 2 * (lane & 3) + t_kk;
             float d[8], t[8];
             if (DIR == 0) {
@@ -179,13 +183,13 @@ __global__ __launch_bounds__(NT) void wino1d_kernel(const float* __restrict__ x,
     };
     auto multiply = [&](int buf) {
         const float* vb = Vs + buf * V_FLOATS + wave * V_XI + (lane >> 5) * (TILES * 4) + (lane & 31) * 4;
-        float4 b[4];
+        float4 b[NTG];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const float4*>(vb + nt * 128);
+        for (int nt = 0; nt < NTG; ++nt) b[nt] = *reinterpret_cast<const float4*>(vb + nt * 128);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NTG; ++nt) {
                 const float bv = ks == 0 ? b[nt].x : ks == 1 ? b[nt].y : ks == 2 ? b[nt].z : b[nt].w;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(NT) void wino1d_kernel(const float* __restrict__ x,
     auto put_m = [&](int q) {
         float* mb = lds + (q & 1) * M_FLOATS + wave * (TILES * 16);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTG; ++nt)
 #pragma unroll
             for (int eh = 0; eh < 2; ++eh) {
                 const int e = (q & 1) * 8 + eh * 4, g = 2 * eh + kk, tile = nt * 32 + nn;
@@ -236,13 +240,13 @@ __global__ __launch_bounds__(NT) void wino1d_kernel(const float* __restrict__ x,
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q < 3) put_m(q + 1);
-        const int tile = tid & 127;
+        const int tile = tid & (TILES - 1);
         int oy, ox;
-        if (DIR == 0) { oy = by * 32 + (tile >> 2); ox = bx * 16 + 4 * (tile & 3); }
-        else { oy = by * 32 + 4 * (tile >> 4); ox = bx * 16 + (tile & 15); }
+        if (DIR == 0) { oy = by * ROWS + (tile >> 2); ox = bx * 16 + 4 * (tile & 3); }
+        else { oy = by * ROWS + 4 * (tile >> 4); ox = bx * 16 + (tile & 15); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kq = (tid >> 7) + 4 * j;
+        for (int j = 0; j < 16 * TILES / NT; ++j) {
+            const int kq = tid / TILES + (NT / TILES) * j;
             const int k = kb * KB + q * 16 + kq;
             const float* mp = lds + (q & 1) * M_FLOATS + tile * 16 + 4 * ((kq >> 2) ^ ((tile >> 2) & 3)) + (kq & 3);
             float m[8], o[4];
@@ -291,15 +295,18 @@ extern "C" int vo_conv5_winograd(const float* x, const float* transformed, float
     if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv5_winograd: C=%d is not a multiple of %d", C, CB);
     if ((int64_t)C * H * W * 4 >= 0x7fffffffLL)
         return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv5_winograd: one image of the input exceeds 2 GiB");
-    const int bx = (W + 15) / 16, by = (H + 31) / 32;
+    // 16x16-pixel blocks, two workgroups per CU: equal or faster than 32x16 blocks on every shape measured
+    // (384 -> 128 @60x80x32: 0.34 vs 0.42 ms, the smaller blocks also even out the last round of workgroups)
+    constexpr int NTG = 2;
+    const int rows = 8 * NTG;
+    const int bx = (W + 15) / 16, by = (H + rows - 1) / rows;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv5_winograd: grid too large");
     const dim3 grid((unsigned)(blocks * kblocks));
-    if (vertical)
-        wino1d_kernel<1><<<grid, dim3(NT), 0, vo_stream(stream)>>>(x, transformed, y, C, H, W, K, bx, by, kblocks);
-    else
-        wino1d_kernel<0><<<grid, dim3(NT), 0, vo_stream(stream)>>>(x, transformed, y, C, H, W, K, bx, by, kblocks);
+    hipStream_t st = vo_stream(stream);
+    if (vertical) wino1d_kernel<1, NTG><<<grid, dim3(NT), 0, st>>>(x, transformed, y, C, H, W, K, bx, by, kblocks);
+    else wino1d_kernel<0, NTG><<<grid, dim3(NT), 0, st>>>(x, transformed, y, C, H, W, K, bx, by, kblocks);
     VO_CHECK_LAUNCH("vo_conv5_winograd");
     return VO_OK;
 }
