@@ -150,6 +150,18 @@ int vo_winograd1d_filter(const float* weight, float* transformed, int K, int C, 
 int vo_conv5_winograd(const float* x, const float* transformed, float* y, int N, int C, int H, int W, int K,
                       int vertical, void* stream);
 
+/* 1x1 stride-1 float32 convolution, NCHW, as a streaming matrix-core GEMM (no LDS): the motion
+ * encoders' first layers, projection shortcuts and mask heads of the models built at
+ * flow/flow_map_RAFT.py:42 and stereo/stereo_disparity_RAFT.py:46, and the per-tap planes of the
+ * two-channel flow heads.
+ *   vo_conv1x1_filter  weight (K,C) -> weights in matrix-operand order, ceil(K/64)*64 * ceil(C/8)*8 floats.
+ *   vo_conv1x1         x (N,C,P), P = H*W pixels -> y (N,K,P): v = sum_c W[k,c] x[c,p]; then
+ *                      v*scale[k] + shift[k] (either may be NULL) and ReLU when relu != 0.  y may be a
+ *                      channel slice of a wider tensor (items y_batch_stride ELEMENTS apart, 0 = dense). */
+int vo_conv1x1_filter(const float* weight, float* arranged, int K, int C, void* stream);
+int vo_conv1x1(const float* x, const float* arranged, float* y, int64_t y_batch_stride, const float* scale,
+               const float* shift, int relu, int N, int C, int64_t P, int K, void* stream);
+
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one
  * plane per filter tap, planes (N, K*9, H, W) in (k, r, s) order; this pass adds the nine

@@ -635,3 +635,33 @@ def test_separable_gru_on_the_winograd_kernel(vo):
         with fused_passes():
             b = gru(h, xin)
     assert (a - b).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 8, 5, 7, 64), (2, 13, 33, 21, 40), (2, 36, 30, 41, 18), (3, 324, 15, 20, 256),
+                                       (1, 5, 1, 1, 3), (2, 64, 24, 32, 96)])
+def test_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
+    """The streaming MFMA 1x1 convolution against the float64 convolution: channel counts that are
+    no multiple of 8, odd pixel counts, partial channel blocks; scale / shift / ReLU at the store;
+    output into a channel slice."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=130).to(DEV)
+    w = (_rand(K, C, 1, 1, seed=131) / C ** 0.5).to(DEV)
+    scale, shift = _rand(K, seed=132).to(DEV), _rand(K, seed=133).to(DEV)
+    Wg = ops.conv1x1_filter(w)
+    ref = Fn.conv2d(x.double(), w.double())
+    tol = 1e-5 * max(1.0, ref.abs().max().item())
+    b = lambda v: v.double()[None, :, None, None]
+    assert (ops.conv1x1(x, Wg, K).double() - ref).abs().max().item() < tol
+    assert (ops.conv1x1(x, Wg, K, None, shift, True).double() - torch.relu(ref + b(shift))).abs().max().item() < tol
+    got = ops.conv1x1(x, Wg, K, scale, shift, False)
+    assert (got.double() - (ref * b(scale) + b(shift))).abs().max().item() < 3 * tol
+    assert torch.equal(got, ops.conv1x1(x, Wg, K, scale, shift, False))
+    wide = torch.full((N, 3 + K + 2, H, W), 7.5, device=DEV)
+    ops.conv1x1(x, Wg, K, None, shift, True, out=wide[:, 3:3 + K])
+    assert (wide[:, 3:3 + K].double() - torch.relu(ref + b(shift))).abs().max().item() < tol
+    assert torch.all(wide[:, :3] == 7.5) and torch.all(wide[:, 3 + K:] == 7.5)
+    with pytest.raises(ValueError):
+        ops.conv1x1(x, Wg[:-1].contiguous(), K)
+    with pytest.raises(ValueError):
+        ops.conv1x1(x, Wg, K, None, shift[:-1].contiguous())

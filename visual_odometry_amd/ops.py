@@ -294,6 +294,37 @@ def conv5_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, vertical:
     return out
 
 
+def conv1x1_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,1,1) or (K,C) float32 weight -> the arranged weights conv1x1 consumes."""
+    if weight.dim() not in (2, 4) or (weight.dim() == 4 and tuple(weight.shape[2:]) != (1, 1)):
+        raise ValueError("weight must be (K,C,1,1) or (K,C)")
+    K, C = weight.shape[:2]
+    out = torch.empty(((K + 63) // 64 * 64 * ((C + 7) // 8 * 8),), device=weight.device, dtype=torch.float32)
+    _call("vo_conv1x1_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    return out
+
+
+def conv1x1(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+            shift: torch.Tensor | None = None, relu: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """x (N,C,H,W) float32, arranged (K,C) weights -> conv2d(x, weight) [* scale[k] + shift[k]] [ReLU].
+    ``out`` may be a channel slice of a wider NCHW tensor."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * ((C + 7) // 8 * 8):
+        raise ValueError("arranged weights do not match (K, C)")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    if out is None:
+        out = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (N, K, H, W) or out.dtype != torch.float32:
+        raise ValueError("out must be float32 (N,K,H,W)")
+    py, sy = _slice(out, "out")
+    _call("vo_conv1x1", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), py, sy,
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H * W, K, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * N * K * C * H * W)
+    return out
+
+
 def shift_add_3x3(planes: torch.Tensor, bias: torch.Tensor | None, K: int) -> torch.Tensor:
     """planes (N, K*9, H, W): per-tap 1x1 products in (k, r, s) order -> the 3x3 / padding 1
     convolution output (N, K, H, W) (+ bias)."""

@@ -67,6 +67,9 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
             U = _winograd_filter_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if U is not None:
                 return ops.conv3x3_winograd(x, U, conv.out_channels, None, conv.bias, False)
+            Wg = _conv1x1_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Wg is not None:
+                return ops.conv1x1(x, Wg, conv.out_channels, None, conv.bias, False)
             if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                     and conv.groups == 1 and conv.out_channels <= 4 and x.is_contiguous()):
                 # very few output channels (the flow heads): a 1x1 convolution with one output plane
@@ -78,7 +81,10 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
                     K, C = conv.weight.shape[:2]
                     cached = (key, conv.weight.detach().permute(0, 2, 3, 1).reshape(K * 9, C, 1, 1).contiguous())
                     conv._vo_taps = cached
-                return ops.shift_add_3x3(F.conv2d(x, cached[1]), conv.bias, conv.out_channels)
+                taps = cached[1]
+                Wg = _conv1x1_weights_for(x, taps, (1, 1), (0, 0), (1, 1), 1)
+                planes = ops.conv1x1(x, Wg, taps.shape[0]) if Wg is not None else F.conv2d(x, taps)
+                return ops.shift_add_3x3(planes, conv.bias, conv.out_channels)
         return conv(x)
     w = weight_for(conv, x)
     return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
@@ -133,6 +139,22 @@ def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
     return U
 
 
+def _conv1x1_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
+    """The cached arranged weights when this convolution can run on the streaming 1x1 matrix-core
+    kernel (1x1 / stride 1 / no padding, float32, contiguous input), else None."""
+    if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+            and tuple(weight.shape[2:]) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
+            and (x.shape[1] + 8) * x.shape[2] * x.shape[3] * 4 < 2 ** 31):
+        return None
+    key = (weight._version, weight.data_ptr())
+    cached = getattr(weight, "_vo_conv1x1", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.conv1x1_filter(weight))
+        weight._vo_conv1x1 = cached
+    return cached[1]
+
+
 def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
                   groups: int = 1) -> torch.Tensor:
     """Bias-free convolution inside the fused path: eligible 3x3 layers on the Winograd
@@ -140,6 +162,9 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     U = _winograd_filter_for(x, weight, stride, padding, dilation, groups)
     if U is not None:
         return ops.conv3x3_winograd(x, U, weight.shape[0])
+    Wg = _conv1x1_weights_for(x, weight, stride, padding, dilation, groups)
+    if Wg is not None:
+        return ops.conv1x1(x, Wg, weight.shape[0])
     ks = tuple(weight.shape[2:])
     if (_WINOGRAD and ks in ((1, 5), (5, 1)) and tuple(padding) == (ks[0] // 2, ks[1] // 2) and tuple(stride) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and x.dtype == torch.float32 and weight.dtype == torch.float32
@@ -165,6 +190,10 @@ def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor
     U = _winograd_filter_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
     if U is not None and (skip is None or (skip.dtype == torch.float32 and skip.is_contiguous())):
         return ops.conv3x3_winograd(x, U, w.shape[0], scale, shift, relu, skip, out)
+    if skip is None:
+        Wg = _conv1x1_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if Wg is not None:
+            return ops.conv1x1(x, Wg, w.shape[0], scale, shift, relu, out)
     y = _conv_nobias(x, conv)
     if scale is None:
         scale = getattr(conv, "_vo_ones", None)
@@ -183,7 +212,7 @@ def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
         # a strided 1x1 convolution only ever reads the sampled pixels: gather them once and
         # run a dense GEMM instead of MIOpen's strided 1x1 path (18 TFLOP/s on these shapes)
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]].contiguous()
-        return F.conv2d(x, weight_for(conv, x), None, 1, 0, conv.dilation, conv.groups)
+        return conv2d_nobias(x, weight_for(conv, x), (1, 1), (0, 0), conv.dilation, conv.groups)
     return conv2d_nobias(x, weight_for(conv, x), conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
