@@ -325,6 +325,32 @@ def conv1x1(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor
     return out
 
 
+def conv7x7_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,7,7) float32 weight, C <= 8 -> the arranged weights conv7x7 consumes."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (7, 7) or weight.shape[1] > 8:
+        raise ValueError("weight must be (K,C,7,7) with at most 8 input channels")
+    K, C = weight.shape[:2]
+    out = torch.empty(((K + 63) // 64 * 64 * C * 56,), device=weight.device, dtype=torch.float32)
+    _call("vo_conv7x7_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    return out
+
+
+def conv7x7(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+            shift: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
+    """x (N,C,H,W) float32, C <= 8 -> conv2d(x, weight, padding=3) [* scale[k] + shift[k]] [ReLU]."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C * 56:
+        raise ValueError("arranged weights do not match (K, C)")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    out = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    _call("vo_conv7x7", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * N * K * C * 49 * H * W)
+    return out
+
+
 def shift_add_3x3(planes: torch.Tensor, bias: torch.Tensor | None, K: int) -> torch.Tensor:
     """planes (N, K*9, H, W): per-tap 1x1 products in (k, r, s) order -> the 3x3 / padding 1
     convolution output (N, K, H, W) (+ bias)."""
