@@ -162,16 +162,16 @@ int vo_conv1x1_filter(const float* weight, float* arranged, int K, int C, void* 
 int vo_conv1x1(const float* x, const float* arranged, float* y, int64_t y_batch_stride, const float* scale,
                const float* shift, int relu, int N, int C, int64_t P, int K, void* stream);
 
-/* 7x7 stride-1 padding-3 float32 convolution with at most 8 input channels, NCHW, as a streaming
- * matrix-core GEMM (no LDS): the stems of RAFT-Stereo's encoders (3 -> 64 at full resolution) and
- * the motion encoders' flow branch (2 -> 64 / 128) of the models built at
+/* 7x7 padding-3 float32 convolution (stride 1 or 2) with at most 8 input channels, NCHW, as a
+ * streaming matrix-core GEMM (no LDS): the stems of the encoders (3 -> 64 at full resolution,
+ * stride 1 in RAFT-Stereo, 2 in RAFT) and the motion encoders' flow branch (2 -> 64 / 128) of the models built at
  * stereo/stereo_disparity_RAFT.py:46 and flow/flow_map_RAFT.py:42.
  *   vo_conv7x7_filter  weight (K,C,7,7) -> weights in matrix-operand order, ceil(K/64)*64 * C * 56 floats.
- *   vo_conv7x7         x (N,C,H,W) -> y (N,K,H,W), then v*scale[k] + shift[k] (either may be NULL)
- *                      and ReLU when relu != 0. */
+ *   vo_conv7x7         x (N,C,H,W) -> y (N,K,Ho,Wo), Ho = (H-1)/stride + 1, then v*scale[k] + shift[k]
+ *                      (either may be NULL) and ReLU when relu != 0. */
 int vo_conv7x7_filter(const float* weight, float* arranged, int K, int C, void* stream);
 int vo_conv7x7(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
-               int N, int C, int H, int W, int K, void* stream);
+               int N, int C, int H, int W, int K, int stride, void* stream);
 
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one

@@ -669,24 +669,25 @@ def test_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
 
 @pytest.mark.parametrize("N,C,H,W,K", [(1, 3, 5, 7, 64), (2, 2, 33, 70, 40), (2, 3, 9, 130, 100), (1, 1, 2, 3, 5),
                                        (2, 3, 64, 96, 64)])
-def test_conv7x7_matches_the_stock_convolution(vo, N, C, H, W, K):
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv7x7_matches_the_stock_convolution(vo, N, C, H, W, K, stride):
     """The streaming MFMA 7x7 convolution (stems, motion encoders' flow branch) against the float64
-    convolution: images smaller than the filter, widths that are no multiple of the 64-pixel row
-    segment, partial channel blocks; scale / shift / ReLU at the store."""
+    convolution, stride 1 and 2: images smaller than the filter, odd sizes, widths that are no
+    multiple of the 64-pixel row segment, partial channel blocks; scale / shift / ReLU at the store."""
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops
     x = _rand(N, C, H, W, seed=140).to(DEV)
     w = (_rand(K, C, 7, 7, seed=141) / (49 * C) ** 0.5).to(DEV)
     scale, shift = _rand(K, seed=142).to(DEV), _rand(K, seed=143).to(DEV)
     Wg = ops.conv7x7_filter(w)
-    ref = Fn.conv2d(x.double(), w.double(), None, 1, 3)
+    ref = Fn.conv2d(x.double(), w.double(), None, stride, 3)
     tol = 1e-5 * max(1.0, ref.abs().max().item())
     b = lambda v: v.double()[None, :, None, None]
-    got = ops.conv7x7(x, Wg, K)
+    got = ops.conv7x7(x, Wg, K, stride=stride)
     assert got.shape == ref.shape and (got.double() - ref).abs().max().item() < tol
-    assert (ops.conv7x7(x, Wg, K, None, shift, True).double() - torch.relu(ref + b(shift))).abs().max().item() < tol
-    assert (ops.conv7x7(x, Wg, K, scale, shift, False).double() - (ref * b(scale) + b(shift))).abs().max().item() < 3 * tol
-    assert torch.equal(got, ops.conv7x7(x, Wg, K))
+    assert (ops.conv7x7(x, Wg, K, None, shift, True, stride).double() - torch.relu(ref + b(shift))).abs().max().item() < tol
+    assert (ops.conv7x7(x, Wg, K, scale, shift, False, stride).double() - (ref * b(scale) + b(shift))).abs().max().item() < 3 * tol
+    assert torch.equal(got, ops.conv7x7(x, Wg, K, stride=stride))
     with pytest.raises(ValueError):
         ops.conv7x7_filter(_rand(8, 9, 7, 7, seed=1).to(DEV))
     with pytest.raises(ValueError):

@@ -7,7 +7,7 @@ from visual_odometry_amd import _lib
 lib = _lib.load()
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.vo_conv7x7_filter.argtypes = [vp, vp, ci, ci, vp]; lib.vo_conv7x7_filter.restype = ci
-lib.vo_conv7x7.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.vo_conv7x7.restype = ci
+lib.vo_conv7x7.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]; lib.vo_conv7x7.restype = ci
 shapes = [(1, 3, 5, 7, 64), (2, 2, 33, 70, 40), (2, 3, 9, 130, 100), (64, 3, 480, 640, 64), (32, 3, 480, 640, 64),
           (32, 2, 120, 160, 64), (32, 2, 60, 80, 128)]
 if len(sys.argv) > 1: shapes = shapes[:int(sys.argv[1])]
@@ -24,7 +24,7 @@ for (N, C, H, W, K) in shapes:
     assert lib.vo_conv7x7_filter(w.data_ptr(), Wg.data_ptr(), K, C, s) == 0
     y = torch.empty(N, K, H, W, device="cuda")
     def run():
-        assert lib.vo_conv7x7(x.data_ptr(), Wg.data_ptr(), y.data_ptr(), None, b.data_ptr(), 1, N, C, H, W, K, s) == 0
+        assert lib.vo_conv7x7(x.data_ptr(), Wg.data_ptr(), y.data_ptr(), None, b.data_ptr(), 1, N, C, H, W, K, 1, s) == 0
     run()
     want = torch.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 3))
     scale = want.abs().max().item()

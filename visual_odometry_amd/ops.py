@@ -336,18 +336,22 @@ def conv7x7_filter(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv7x7(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
-            shift: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
-    """x (N,C,H,W) float32, C <= 8 -> conv2d(x, weight, padding=3) [* scale[k] + shift[k]] [ReLU]."""
+            shift: torch.Tensor | None = None, relu: bool = False, stride: int = 1) -> torch.Tensor:
+    """x (N,C,H,W) float32, C <= 8 -> conv2d(x, weight, stride=stride, padding=3) [* scale[k] + shift[k]] [ReLU];
+    stride 1 or 2."""
     N, C, H, W = x.shape
+    if stride not in (1, 2):
+        raise ValueError("stride must be 1 or 2")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if arranged.numel() != (K + 63) // 64 * 64 * C * 56:
         raise ValueError("arranged weights do not match (K, C)")
     for t, name in ((scale, "scale"), (shift, "shift")):
         if t is not None and t.numel() != K:
             raise ValueError(f"{name} must have one entry per output channel")
-    out = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
     _call("vo_conv7x7", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
-          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
-          nbytes=4 * (x.numel() + out.numel()), flops=2 * N * K * C * 49 * H * W)
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, stride,
+          _stream(), nbytes=4 * (x.numel() + out.numel()), flops=2 * N * K * C * 49 * Ho * Wo)
     return out
 
 

@@ -72,7 +72,7 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
                 return ops.conv1x1(x, Wg, conv.out_channels, None, conv.bias, False)
             Wg = _conv7x7_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
-                return ops.conv7x7(x, Wg, conv.out_channels, None, conv.bias, False)
+                return ops.conv7x7(x, Wg, conv.out_channels, None, conv.bias, False, conv.stride[0])
             if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                     and conv.groups == 1 and conv.out_channels <= 4 and x.is_contiguous()):
                 # very few output channels (the flow heads): a 1x1 convolution with one output plane
@@ -160,9 +160,9 @@ def _conv1x1_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
 
 def _conv7x7_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached arranged weights when this convolution can run on the streaming 7x7 matrix-core
-    kernel (7x7 / stride 1 / padding 3, at most 8 input channels, float32), else None."""
+    kernel (7x7 / stride 1 or 2 / padding 3, at most 8 input channels, float32), else None."""
     if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
-            and tuple(weight.shape[2:]) == (7, 7) and tuple(stride) == (1, 1) and tuple(padding) == (3, 3)
+            and tuple(weight.shape[2:]) == (7, 7) and tuple(stride) in ((1, 1), (2, 2)) and tuple(padding) == (3, 3)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] <= 8
             and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
         return None
@@ -186,7 +186,7 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
         return ops.conv1x1(x, Wg, weight.shape[0])
     Wg = _conv7x7_weights_for(x, weight, stride, padding, dilation, groups)
     if Wg is not None:
-        return ops.conv7x7(x, Wg, weight.shape[0])
+        return ops.conv7x7(x, Wg, weight.shape[0], stride=tuple(stride)[0])
     ks = tuple(weight.shape[2:])
     if (_WINOGRAD and ks in ((1, 5), (5, 1)) and tuple(padding) == (ks[0] // 2, ks[1] // 2) and tuple(stride) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and x.dtype == torch.float32 and weight.dtype == torch.float32
@@ -219,7 +219,7 @@ def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor
         if out is None:
             Wg = _conv7x7_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
-                return ops.conv7x7(x, Wg, w.shape[0], scale, shift, relu)
+                return ops.conv7x7(x, Wg, w.shape[0], scale, shift, relu, conv.stride[0])
     y = _conv_nobias(x, conv)
     if scale is None:
         scale = getattr(conv, "_vo_ones", None)
