@@ -173,6 +173,16 @@ int vo_conv7x7_filter(const float* weight, float* arranged, int K, int C, void* 
 int vo_conv7x7(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
                int N, int C, int H, int W, int K, int stride, void* stream);
 
+/* 3x3 stride-2 padding-1 float32 convolution, NCHW, as a streaming matrix-core GEMM (no LDS): the
+ * downsampling layers of the encoders' residual stages (models built at flow/flow_map_RAFT.py:42,
+ * stereo/stereo_disparity_RAFT.py:46).  C must be a multiple of 8.
+ *   vo_conv3x3s2_filter  weight (K,C,3,3) -> weights in matrix-operand order, ceil(K/64)*64 * C * 9 floats.
+ *   vo_conv3x3s2         x (N,C,H,W) -> y (N,K,Ho,Wo), Ho = (H-1)/2 + 1, then v*scale[k] + shift[k]
+ *                        (either may be NULL) and ReLU when relu != 0. */
+int vo_conv3x3s2_filter(const float* weight, float* arranged, int K, int C, void* stream);
+int vo_conv3x3s2(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
+                 int N, int C, int H, int W, int K, void* stream);
+
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one
  * plane per filter tap, planes (N, K*9, H, W) in (k, r, s) order; this pass adds the nine

@@ -692,3 +692,29 @@ def test_conv7x7_matches_the_stock_convolution(vo, N, C, H, W, K, stride):
         ops.conv7x7_filter(_rand(8, 9, 7, 7, seed=1).to(DEV))
     with pytest.raises(ValueError):
         ops.conv7x7(x, Wg[:-1].contiguous(), K)
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 8, 5, 7, 64), (2, 16, 33, 70, 40), (2, 24, 9, 131, 100), (1, 8, 1, 1, 3),
+                                       (2, 64, 48, 256, 96)])
+def test_conv3x3s2_matches_the_stock_convolution(vo, N, C, H, W, K):
+    """The streaming MFMA 3x3 stride-2 convolution (encoders' downsampling layers) against the float64
+    convolution: odd and even sizes, a single pixel, partial channel blocks (one k-tile launch);
+    scale / shift / ReLU at the store."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=150).to(DEV)
+    w = (_rand(K, C, 3, 3, seed=151) / (9 * C) ** 0.5).to(DEV)
+    scale, shift = _rand(K, seed=152).to(DEV), _rand(K, seed=153).to(DEV)
+    Wg = ops.conv3x3s2_filter(w)
+    ref = Fn.conv2d(x.double(), w.double(), None, 2, 1)
+    tol = 1e-5 * max(1.0, ref.abs().max().item())
+    b = lambda v: v.double()[None, :, None, None]
+    got = ops.conv3x3s2(x, Wg, K)
+    assert got.shape == ref.shape and (got.double() - ref).abs().max().item() < tol
+    assert (ops.conv3x3s2(x, Wg, K, None, shift, True).double() - torch.relu(ref + b(shift))).abs().max().item() < tol
+    assert (ops.conv3x3s2(x, Wg, K, scale, shift, False).double() - (ref * b(scale) + b(shift))).abs().max().item() < 3 * tol
+    assert torch.equal(got, ops.conv3x3s2(x, Wg, K))
+    with pytest.raises(ValueError):
+        ops.conv3x3s2_filter(_rand(8, 6, 3, 3, seed=1).to(DEV))
+    with pytest.raises(ValueError):
+        ops.conv3x3s2(x, Wg[:-1].contiguous(), K)

@@ -355,6 +355,33 @@ def conv7x7(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor
     return out
 
 
+def conv3x3s2_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,3,3) float32 weight, C a multiple of 8 -> the arranged weights conv3x3s2 consumes."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] % 8:
+        raise ValueError("weight must be (K,C,3,3) with a multiple of 8 input channels")
+    K, C = weight.shape[:2]
+    out = torch.empty(((K + 63) // 64 * 64 * C * 9,), device=weight.device, dtype=torch.float32)
+    _call("vo_conv3x3s2_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    return out
+
+
+def conv3x3s2(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+              shift: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
+    """x (N,C,H,W) float32 -> conv2d(x, weight, stride=2, padding=1) [* scale[k] + shift[k]] [ReLU]."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C * 9:
+        raise ValueError("arranged weights do not match (K, C)")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
+    _call("vo_conv3x3s2", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * N * K * C * 9 * Ho * Wo)
+    return out
+
+
 def shift_add_3x3(planes: torch.Tensor, bias: torch.Tensor | None, K: int) -> torch.Tensor:
     """planes (N, K*9, H, W): per-tap 1x1 products in (k, r, s) order -> the 3x3 / padding 1
     convolution output (N, K, H, W) (+ bias)."""

@@ -73,6 +73,9 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
             Wg = _conv7x7_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv7x7(x, Wg, conv.out_channels, None, conv.bias, False, conv.stride[0])
+            Wg = _conv3x3s2_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Wg is not None:
+                return ops.conv3x3s2(x, Wg, conv.out_channels, None, conv.bias, False)
             if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                     and conv.groups == 1 and conv.out_channels <= 4 and x.is_contiguous()):
                 # very few output channels (the flow heads): a 1x1 convolution with one output plane
@@ -174,6 +177,26 @@ def _conv7x7_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
     return cached[1]
 
 
+def _conv3x3s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
+    """The cached arranged weights when this convolution can run on the streaming 3x3 stride-2
+    matrix-core kernel (float32, input channels a multiple of 8, an output width that fills the
+    kernel's 64-pixel row segments to at least 80 %), else None."""
+    if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] % 8 == 0
+            and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
+        return None
+    wo = (x.shape[3] - 1) // 2 + 1
+    if wo < 0.8 * ((wo + 63) // 64 * 64):
+        return None
+    key = (weight._version, weight.data_ptr())
+    cached = getattr(weight, "_vo_conv3x3s2", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.conv3x3s2_filter(weight))
+        weight._vo_conv3x3s2 = cached
+    return cached[1]
+
+
 def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
                   groups: int = 1) -> torch.Tensor:
     """Bias-free convolution inside the fused path: eligible 3x3 layers on the Winograd
@@ -187,6 +210,9 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     Wg = _conv7x7_weights_for(x, weight, stride, padding, dilation, groups)
     if Wg is not None:
         return ops.conv7x7(x, Wg, weight.shape[0], stride=tuple(stride)[0])
+    Wg = _conv3x3s2_weights_for(x, weight, stride, padding, dilation, groups)
+    if Wg is not None:
+        return ops.conv3x3s2(x, Wg, weight.shape[0])
     ks = tuple(weight.shape[2:])
     if (_WINOGRAD and ks in ((1, 5), (5, 1)) and tuple(padding) == (ks[0] // 2, ks[1] // 2) and tuple(stride) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and x.dtype == torch.float32 and weight.dtype == torch.float32
@@ -220,6 +246,9 @@ def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor
             Wg = _conv7x7_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv7x7(x, Wg, w.shape[0], scale, shift, relu, conv.stride[0])
+            Wg = _conv3x3s2_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Wg is not None:
+                return ops.conv3x3s2(x, Wg, w.shape[0], scale, shift, relu)
     y = _conv_nobias(x, conv)
     if scale is None:
         scale = getattr(conv, "_vo_ones", None)
