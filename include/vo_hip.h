@@ -182,6 +182,10 @@ int vo_conv7x7(const float* x, const float* arranged, float* y, const float* sca
 int vo_conv3x3s2_filter(const float* weight, float* arranged, int K, int C, void* stream);
 int vo_conv3x3s2(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
                  int N, int C, int H, int W, int K, void* stream);
+/* The 1x1 stride-2 convolution of the same stages' projection shortcuts, on the same kernel with a
+ * single tap: weights arranged by vo_conv1x1_filter (C a multiple of 8), x (N,C,H,W) -> y (N,K,Ho,Wo). */
+int vo_conv1x1s2(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
+                 int N, int C, int H, int W, int K, void* stream);
 
 /* 3x3 / padding 1 convolutions with very few output channels (the flow heads' last
  * layer, 256 -> 2): the framework runs a 1x1 convolution with 9K output channels, one

@@ -718,3 +718,8 @@ def test_conv3x3s2_matches_the_stock_convolution(vo, N, C, H, W, K):
         ops.conv3x3s2_filter(_rand(8, 6, 3, 3, seed=1).to(DEV))
     with pytest.raises(ValueError):
         ops.conv3x3s2(x, Wg[:-1].contiguous(), K)
+    # the projection shortcut: 1x1, stride 2, on the same kernel with one tap
+    w1 = (_rand(K, C, 1, 1, seed=154) / C ** 0.5).to(DEV)
+    ref1 = Fn.conv2d(x.double(), w1.double(), None, 2, 0)
+    got1 = ops.conv1x1s2(x, ops.conv1x1_filter(w1), K, None, shift, False)
+    assert got1.shape == ref1.shape and (got1.double() - (ref1 + b(shift))).abs().max().item() < 1e-5 * max(1.0, ref1.abs().max().item())

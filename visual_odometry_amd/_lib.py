@@ -38,6 +38,7 @@ SIGNATURES = {
     "vo_conv7x7": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv3x3s2_filter": [_P, _P, _I, _I, _P],
     "vo_conv3x3s2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv1x1s2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_shift_add_3x3": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_gru_gates": [_P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _L, _I, _P],
     "vo_gru_update": [_P, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _I, _L, _I, _P],

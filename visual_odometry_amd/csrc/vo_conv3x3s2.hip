@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void filter3s2_kernel(const float* __restrict_
 struct Epi { const float* scale; const float* shift; int relu; };
 
 // KT: k-tiles of 32 output channels per wave (1 for a last block with at most 32 channels).
-template <int KT>
+// ONE_TAP: the 1x1 stride-2 convolution of the projection shortcuts (only the centre tap exists; the
+// weights are in vo_conv1x1_filter's order, which is this kernel's order with a single tap).
+template <int KT, bool ONE_TAP>
 __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                       float* __restrict__ y, Epi ep, int C, int H, int W, int Ho, int Wo, int K,
                                                       int blocks_x, int blocks_y, int kblocks, int kb_base) {
@@ -56,8 +58,9 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
 
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (int64_t)n * C * H * W), 0, C * plane, 0x00020000);
+    constexpr int TAPS = ONE_TAP ? 1 : 9;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Wg + (int64_t)kb * 9 * nchunks * 512), 0, 9 * nchunks * 512 * 4, 0x00020000);
+        const_cast<float*>(Wg + (int64_t)kb * TAPS * nchunks * 512), 0, TAPS * nchunks * 512 * 4, 0x00020000);
     // lane part of the byte offset of the element (filter column s, pixel tile t): the lane's channel
     // parity plane plus the column, or OOB for the padding columns
     int coff[3][2];
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
             for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.0f;
 
     const int iy = 2 * py - 1;                                   // input row of filter row 0
-    const int r_lo = iy < 0 ? 1 : 0, r_hi = iy + 2 >= H ? H - 1 - iy : 2;           // valid filter rows
+    const int r_lo = ONE_TAP ? 1 : (iy < 0 ? 1 : 0), r_hi = ONE_TAP ? 1 : (iy + 2 >= H ? H - 1 - iy : 2);   // valid filter rows
     const int total = (r_hi - r_lo + 1) * nchunks;               // (filter row, chunk) pairs; three filter columns each
 
     float bcur[4][2], bnxt[4][2];
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
     int lr = r_lo, lc = 0;                                       // (filter row, chunk) of the loads being issued
     auto load = [&](auto stag) {                                 // the filter column is a compile-time constant
         constexpr int ls = decltype(stag)::value;
-        const int tap = 3 * lr + ls;
+        const int tap = ONE_TAP ? 0 : 3 * lr + ls;
         const int soff = (lc * CB) * plane + (iy + lr) * W * 4;  // wave-uniform: chunk's first plane, input row
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -116,14 +119,24 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
-    load(S0{});
-    for (int i = 0; i < total; ++i) {
-        take(); load(S1{}); step();
-        take(); load(S2{}); step();
-        take();
-        if (++lc == nchunks) { lc = 0; if (lr < r_hi) ++lr; }    // past the end: a valid pair again, never used
+    if (ONE_TAP) {
+        load(S1{});
+        for (int i = 0; i < total; ++i) {
+            take();
+            if (lc + 1 < nchunks) ++lc;                          // past the end: the last chunk again, never used
+            load(S1{});
+            step();
+        }
+    } else {
         load(S0{});
-        step();
+        for (int i = 0; i < total; ++i) {
+            take(); load(S1{}); step();
+            take(); load(S2{}); step();
+            take();
+            if (++lc == nchunks) { lc = 0; if (lr < r_hi) ++lr; }    // past the end: a valid pair again, never used
+            load(S0{});
+            step();
+        }
     }
 
     float* yn = y + (int64_t)n * K * Ho * Wo;
@@ -160,26 +173,39 @@ extern "C" int vo_conv3x3s2_filter(const float* weight, float* arranged, int K, 
     return VO_OK;
 }
 
-extern "C" int vo_conv3x3s2(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
-                            int N, int C, int H, int W, int K, void* stream) {
-    VO_REQUIRE(x && arranged && y, "vo_conv3x3s2: null pointer");
-    VO_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && K > 0, "vo_conv3x3s2: bad sizes");
-    VO_REQUIRE(x != y, "vo_conv3x3s2: the output must not alias the input");
-    if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3s2: C=%d is not a multiple of %d", C, CB);
-    if ((int64_t)C * H * W * 4 >= (int64_t)OOB)
-        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3s2: one image of the input exceeds 1 GiB");
+template <bool ONE_TAP>
+static int launch_s2(const char* name, const float* x, const float* arranged, float* y, const float* scale, const float* shift,
+                     int relu, int N, int C, int H, int W, int K, void* stream) {
+    if (!(x && arranged && y)) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if (!(N > 0 && C > 0 && H > 0 && W > 0 && K > 0)) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes", name);
+    if (x == y) return vo_fail(VO_ERR_INVALID_ARG, "%s: the output must not alias the input", name);
+    if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: C=%d is not a multiple of %d", name, C, CB);
+    if ((int64_t)C * H * W * 4 >= (int64_t)OOB) return vo_fail(VO_ERR_UNSUPPORTED, "%s: one image of the input exceeds 1 GiB", name);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int bx = (Wo + 63) / 64, by = (Ho + 3) / 4, kblocks = (K + KB - 1) / KB;
     const int64_t blocks = (int64_t)bx * by * N;
-    if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3s2: grid too large");
+    if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
     const Epi ep{scale, shift, relu};
     hipStream_t st = vo_stream(stream);
     const int rem = K % KB;
     const int full = (rem >= 1 && rem <= 32) ? kblocks - 1 : kblocks;         // a last block of <= 32 channels: one k-tile
     if (full > 0)
-        conv3s2_kernel<2><<<dim3((unsigned)(blocks * full)), dim3(256), 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx, by, full, 0);
+        conv3s2_kernel<2, ONE_TAP><<<dim3((unsigned)(blocks * full)), dim3(256), 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx,
+                                                                                          by, full, 0);
     if (full < kblocks)
-        conv3s2_kernel<1><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx, by, 1, full);
-    VO_CHECK_LAUNCH("vo_conv3x3s2");
+        conv3s2_kernel<1, ONE_TAP><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx, by, 1,
+                                                                                 full);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;
+}
+
+extern "C" int vo_conv3x3s2(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
+                            int N, int C, int H, int W, int K, void* stream) {
+    return launch_s2<false>("vo_conv3x3s2", x, arranged, y, scale, shift, relu, N, C, H, W, K, stream);
+}
+
+extern "C" int vo_conv1x1s2(const float* x, const float* arranged, float* y, const float* scale, const float* shift, int relu,
+                            int N, int C, int H, int W, int K, void* stream) {
+    return launch_s2<true>("vo_conv1x1s2", x, arranged, y, scale, shift, relu, N, C, H, W, K, stream);
 }

@@ -382,6 +382,24 @@ def conv3x3s2(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tens
     return out
 
 
+def conv1x1s2(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+              shift: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
+    """x (N,C,H,W) float32, C a multiple of 8, weights from conv1x1_filter -> conv2d(x, weight, stride=2)
+    [* scale[k] + shift[k]] [ReLU]: the projection shortcut, reading only the pixels it samples."""
+    N, C, H, W = x.shape
+    if C % 8 or arranged.numel() != (K + 63) // 64 * 64 * C:
+        raise ValueError("arranged weights do not match (K, C), or C is no multiple of 8")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
+    _call("vo_conv1x1s2", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() // 4 + out.numel()), flops=2 * N * K * C * Ho * Wo)
+    return out
+
+
 def shift_add_3x3(planes: torch.Tensor, bias: torch.Tensor | None, K: int) -> torch.Tensor:
     """planes (N, K*9, H, W): per-tap 1x1 products in (k, r, s) order -> the 3x3 / padding 1
     convolution output (N, K, H, W) (+ bias)."""

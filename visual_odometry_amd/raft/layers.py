@@ -266,8 +266,20 @@ def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     if conv.kernel_size == (1, 1) and conv.stride != (1, 1) and conv.padding == (0, 0):
         # a strided 1x1 convolution only ever reads the sampled pixels: gather them once and
         # run a dense GEMM instead of MIOpen's strided 1x1 path (18 TFLOP/s on these shapes)
+        w = weight_for(conv, x)
+        if (_WINOGRAD and conv.stride == (2, 2) and x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_cuda
+                and x.is_contiguous() and x.shape[1] % 8 == 0 and conv.groups == 1 and conv.dilation == (1, 1)
+                and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
+            wo = (x.shape[3] - 1) // 2 + 1
+            if wo >= 0.8 * ((wo + 63) // 64 * 64):               # the kernel works on 64-pixel row segments
+                key = (w._version, w.data_ptr())
+                cached = getattr(w, "_vo_conv1x1", None)
+                if cached is None or cached[0] != key:
+                    cached = (key, ops.conv1x1_filter(w))
+                    w._vo_conv1x1 = cached
+                return ops.conv1x1s2(x, cached[1], w.shape[0])
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]].contiguous()
-        return conv2d_nobias(x, weight_for(conv, x), (1, 1), (0, 0), conv.dilation, conv.groups)
+        return conv2d_nobias(x, w, (1, 1), (0, 0), conv.dilation, conv.groups)
     return conv2d_nobias(x, weight_for(conv, x), conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
