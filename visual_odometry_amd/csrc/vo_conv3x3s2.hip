@@ -1,15 +1,17 @@
 // 3x3 stride-2 padding-1 convolution in float32, NCHW, as a streaming matrix-core GEMM without LDS:
 // the downsampling layers of the encoders' residual stages (64 -> 96 at full resolution, 96 -> 128
-// at half resolution in both networks).
+// at half resolution in both networks), and the 1x1 stride-2 convolution of their projection shortcuts.
 //     y[n,k,py,px] = act(scale[k] * sum_{r,s,c} w[k,c,r,s] x[n,c,2py+r-1,2px+s-1] + shift[k])
 //
-// The reduction runs tap by tap (r, s) and, inside a tap, over chunks of 8 input channels: one
-// 16-byte load of the pre-arranged weights is the A operand of a chunk's four k-steps, and the B
-// operand of k-step ks is the input plane of channel 2ks + (lane >> 5), sampled at every second
-// pixel, read straight from memory.  A wave owns 64 (or 32) output channels x 64 consecutive pixels
-// of one output row (pixel tile t = pixels 2n+t).  Columns outside the image get a lane offset past
-// the buffer's extent (the range check returns 0.0f), rows outside the image are skipped; all
-// address arithmetic of the loop is scalar.  No wave needs another: no LDS, no barrier.
+// A wave owns 64 (or 32) output channels x 64 consecutive pixels of one output row (pixel tile t =
+// pixels 32t..32t+31, so neighbouring lanes read neighbouring input pixels) and needs no other wave: no
+// LDS, no barrier.  The reduction runs over units of (filter row, 4 input channels, all three filter
+// columns): the B operand of k-step j is the input plane of channel 2j + (lane >> 5) sampled at every
+// second pixel, read straight from memory.  On maps of even width one 8-byte load fetches the
+// columns 2px and 2px+1 (filter columns 1 and 2) and a 4-byte load column 2px-1, so every cache line
+// that is fetched is used in full; the kernel is bound by the rate of these loads, not by their
+// latency.  Columns outside the image get a lane offset past the buffer's extent (the range check
+// returns 0.0f), rows outside the image are skipped; all address arithmetic of the loop is scalar.
 #include "vo_common.h"
 
 #include <type_traits>
@@ -18,28 +20,51 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KB = 64;
 constexpr int CB = 8;
 constexpr int OOB = 0x40000000;            // lane offset no image reaches (images are below 1 GiB)
+constexpr int UNIT = 3 * 2 * 64 * 2;       // floats of one unit's weights: [s][kt][lane][j]
 
-// Wg[kb][tap][chunk][kt][lane][ks]:  k = kb*64 + kt*32 + (lane & 31), tap = 3r + s, c = chunk*8 + 2*ks + (lane >> 5)
+// Wg[kb][r][chunk][h][s][kt][lane][j]:  k = kb*64 + kt*32 + (lane & 31),  c = chunk*8 + 2*(2h + j) + (lane >> 5)
 __global__ __launch_bounds__(256) void filter3s2_kernel(const float* __restrict__ w, float* __restrict__ Wg, int K, int C, int Kpad) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Kpad * C * 9) return;
     const int tap = (int)(idx % 9), c = (int)((idx / 9) % C), k = (int)(idx / (9 * C));
     const float v = k < K ? w[((int64_t)k * C + c) * 9 + tap] : 0.0f;
-    const int kb = k >> 6, kt = (k >> 5) & 1, kl = k & 31, chunk = c >> 3, ks = (c & 7) >> 1, kk = c & 1;
+    const int r = tap / 3, sx = tap % 3;
+    const int kb = k >> 6, kt = (k >> 5) & 1, kl = k & 31, chunk = c >> 3, ks = (c & 7) >> 1, kk = c & 1, h = ks >> 1, j = ks & 1;
     const int nchunks = C / CB;
-    Wg[((((((int64_t)kb * 9 + tap) * nchunks + chunk) * 2 + kt) * 64) + kk * 32 + kl) * 4 + ks] = v;
+    Wg[((((((((int64_t)kb * 3 + r) * nchunks + chunk) * 2 + h) * 3 + sx) * 2 + kt) * 64) + kk * 32 + kl) * 2 + j] = v;
 }
 
 struct Epi { const float* scale; const float* shift; int relu; };
 
+// scale / shift / ReLU and store of a wave's accumulators: lane holds the pixels px0 and px0 + 32 of row py
+template <int KT>
+__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[KT][2], float* __restrict__ yn, const Epi& ep, int kb, int kk,
+                                            int K, int Ho, int Wo, int py, int px0) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (k >= K) continue;
+            const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift ? ep.shift[k] : 0.0f;
+            float* q = yn + ((int64_t)k * Ho + py) * Wo + px0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float o = fmaf(acc[kt][t][e], sc, sh);
+                if (ep.relu) o = fmaxf(o, 0.0f);
+                if (px0 + 32 * t < Wo) q[32 * t] = o;
+            }
+        }
+}
+
 // KT: k-tiles of 32 output channels per wave (1 for a last block with at most 32 channels).
-// ONE_TAP: the 1x1 stride-2 convolution of the projection shortcuts (only the centre tap exists; the
-// weights are in vo_conv1x1_filter's order, which is this kernel's order with a single tap).
-template <int KT, bool ONE_TAP>
+// PAIR: the width is even and x is 8-byte aligned, so the columns 2px and 2px+1 come with one load.
+template <int KT, bool PAIR>
 __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                       float* __restrict__ y, Epi ep, int C, int H, int W, int Ho, int Wo, int K,
                                                       int blocks_x, int blocks_y, int kblocks, int kb_base) {
@@ -52,26 +77,26 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
     const int py = by * 4 + wave;                                // this wave's output row
     if (py >= Ho) return;
     const int kk = lane >> 5, nn = lane & 31;
-    const int px0 = bx * 64 + 2 * nn;                            // this lane's first output pixel of the row
+    const int px0 = bx * 64 + nn;                                // this lane's output pixels of the row: px0 and px0 + 32
     const int nchunks = C / CB;
     const int plane = H * W * 4;                                 // bytes of one input plane
 
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (int64_t)n * C * H * W), 0, C * plane, 0x00020000);
-    constexpr int TAPS = ONE_TAP ? 1 : 9;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Wg + (int64_t)kb * TAPS * nchunks * 512), 0, TAPS * nchunks * 512 * 4, 0x00020000);
-    // lane part of the byte offset of the element (filter column s, pixel tile t): the lane's channel
-    // parity plane plus the column, or OOB for the padding columns
+    const int kb_floats = 3 * nchunks * 2 * UNIT;
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wg + (int64_t)kb * kb_floats), 0, kb_floats * 4, 0x00020000);
+    // lane part of the byte offsets (the lane's channel parity plane plus the column), or OOB for padding:
+    // PAIR: [0] = column 2px-1, [1] = columns 2px, 2px+1 together; otherwise one per filter column
     int coff[3][2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int col = 2 * (px0 + t) + s - 1;
-            coff[s][t] = (col >= 0 && col < W) ? kk * plane + col * 4 : OOB;
+        for (int sx = 0; sx < 3; ++sx) {
+            const int col = 2 * (px0 + 32 * t) + sx - 1;
+            coff[sx][t] = (col >= 0 && col < W) ? kk * plane + col * 4 : OOB;
         }
-    const int w_off = lane * 16;
+    const int w_off = lane * 8;
 
     f32x16 acc[KT][2];
 #pragma unroll
@@ -82,26 +107,147 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
             for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.0f;
 
     const int iy = 2 * py - 1;                                   // input row of filter row 0
-    const int r_lo = ONE_TAP ? 1 : (iy < 0 ? 1 : 0), r_hi = ONE_TAP ? 1 : (iy + 2 >= H ? H - 1 - iy : 2);   // valid filter rows
-    const int total = (r_hi - r_lo + 1) * nchunks;               // (filter row, chunk) pairs; three filter columns each
+    const int r_lo = iy < 0 ? 1 : 0, r_hi = iy + 2 >= H ? H - 1 - iy : 2;          // valid filter rows
+    const int per_row = 2 * nchunks;                             // units of one filter row
+    const int total = (r_hi - r_lo + 1) * per_row;
+
+    // Three operand buffers in rotation: the loads of unit i+3 are issued right after the multiplications
+    // of unit i.  The fences keep that issue order, so each wait covers one buffer's loads.  The loop
+    // body has no branch (the waits stay exact and the accumulators stay in place): the number of units
+    // is rounded up to a multiple of three, and a unit past the end reads its weights from past the
+    // buffer's extent, i.e. multiplies by zero.
+    float b[3][3][2][2];                                         // [buffer][filter column][k-step j][pixel tile]
+    u32x2 a[3][3][KT];                                           // [buffer][filter column][k-tile], the two k-steps each
+    int issued = 0;                                              // units whose loads have been issued
+    auto load = [&](auto btag) {
+        constexpr int lb = decltype(btag)::value;
+        const int u = min(issued, total - 1);                    // past the end: the last unit's input again
+        const int ri = (int)(u >= per_row) + (int)(u >= 2 * per_row);      // branch-free on purpose (see above)
+        const int rest = u - ri * per_row, lr = r_lo + ri;       // rest = 2 * chunk + h
+        // wave-uniform, said explicitly so that no load is wrapped in a loop over lanes
+        const int soff = __builtin_amdgcn_readfirstlane(rest * 4 * plane + (iy + lr) * W * 4);
+        const int woff = __builtin_amdgcn_readfirstlane((lr * per_row + rest) * (UNIT * 4));
+        const int wv = issued < total ? w_off : OOB;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                a[lb][sx][kt] = __builtin_amdgcn_raw_buffer_load_b64(wrs, wv + (sx * 2 + kt) * 512, woff, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                b[lb][0][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[0][t], soff + 2 * j * plane, 0));
+                if (PAIR) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, coff[1][t], soff + 2 * j * plane, 0);
+                    b[lb][1][j][t] = __uint_as_float(v[0]);
+                    b[lb][2][j][t] = __uint_as_float(v[1]);
+                } else {
+                    b[lb][1][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[1][t], soff + 2 * j * plane, 0));
+                    b[lb][2][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[2][t], soff + 2 * j * plane, 0));
+                }
+            }
+        ++issued;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](auto btag) {
+        constexpr int lb = decltype(btag)::value;
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[lb][sx][kt][j]), b[lb][sx][j][t],
+                                                                          acc[kt][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    load(B0{}); load(B1{}); load(B2{});
+    // The compiler interleaves these first loads and would then make every pass of the loop wait as if
+    // they were still in that order.  Naming their registers here makes it wait for them once, before
+    // the loop; with nothing outstanding at the loop's entry the waits inside follow the loop's own order.
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+v"(a[q][sx][kt]));
+            asm volatile("" : "+v"(b[q][sx][0][0]), "+v"(b[q][sx][0][1]), "+v"(b[q][sx][1][0]), "+v"(b[q][sx][1][1]));
+        }
+    for (int i = 0; i < total; i += 3) {
+        step(B0{}); load(B0{});
+        step(B1{}); load(B1{});
+        step(B2{}); load(B2{});
+    }
+
+    store_tiles<KT>(acc, y + (int64_t)n * K * Ho * Wo, ep, kb, kk, K, Ho, Wo, py, px0);
+}
+
+// The 1x1 stride-2 convolution of the projection shortcuts: the same wave tile with a single tap (the
+// centre one) and the reduction over chunks of 8 input channels; the weights are in
+// vo_conv1x1_filter's order, Wg[kb][chunk][kt][lane][ks] with c = chunk*8 + 2*ks + (lane >> 5).
+template <int KT>
+__global__ __launch_bounds__(256) void conv1s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
+                                                      float* __restrict__ y, Epi ep, int C, int H, int W, int Ho, int Wo, int K,
+                                                      int blocks_x, int blocks_y, int kblocks, int kb_base) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bid = blockIdx.x;
+    const int kb = kb_base + bid % kblocks; bid /= kblocks;
+    const int bx = bid % blocks_x; bid /= blocks_x;
+    const int by = bid % blocks_y;
+    const int n = bid / blocks_y;
+    const int py = by * 4 + wave;
+    if (py >= Ho) return;
+    const int kk = lane >> 5, nn = lane & 31;
+    const int px0 = bx * 64 + nn;
+    const int nchunks = C / CB;
+    const int plane = H * W * 4;
+
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (int64_t)n * C * H * W), 0, C * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Wg + (int64_t)kb * nchunks * 512), 0, nchunks * 512 * 4, 0x00020000);
+    int coff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = 2 * (px0 + 32 * t);
+        coff[t] = col < W ? kk * plane + col * 4 : OOB;
+    }
+    const int w_off = lane * 16;
+    const int row = 2 * py * W * 4;                              // the sampled input row
+
+    f32x16 acc[KT][2];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.0f;
 
     float bcur[4][2], bnxt[4][2];
     u32x4 acur[KT], anxt[KT];
-    int lr = r_lo, lc = 0;                                       // (filter row, chunk) of the loads being issued
-    auto load = [&](auto stag) {                                 // the filter column is a compile-time constant
-        constexpr int ls = decltype(stag)::value;
-        const int tap = ONE_TAP ? 0 : 3 * lr + ls;
-        const int soff = (lc * CB) * plane + (iy + lr) * W * 4;  // wave-uniform: chunk's first plane, input row
+    auto load = [&](int chunk) {
+        chunk = chunk < nchunks ? chunk : nchunks - 1;           // past the end: the last chunk again, never used
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-            anxt[kt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_off + kt * 1024, (tap * nchunks + lc) * 2048, 0);
+        for (int kt = 0; kt < KT; ++kt) anxt[kt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_off + kt * 1024, chunk * 2048, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                bnxt[ks][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[ls][t], soff + 2 * ks * plane, 0));
+                bnxt[ks][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[t], (chunk * CB + 2 * ks) * plane + row, 0));
     };
-    auto step = [&]() {                                          // take the loaded operands, multiply
+    load(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acur[kt] = anxt[kt];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { bcur[ks][0] = bnxt[ks][0]; bcur[ks][1] = bnxt[ks][1]; }
+        load(chunk + 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -109,55 +255,9 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
                     acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(acur[kt][ks]), bcur[ks][t], acc[kt][t], 0, 0, 0);
-    };
-    auto take = [&]() {
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) acur[kt] = anxt[kt];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { bcur[ks][0] = bnxt[ks][0]; bcur[ks][1] = bnxt[ks][1]; }
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    if (ONE_TAP) {
-        load(S1{});
-        for (int i = 0; i < total; ++i) {
-            take();
-            if (lc + 1 < nchunks) ++lc;                          // past the end: the last chunk again, never used
-            load(S1{});
-            step();
-        }
-    } else {
-        load(S0{});
-        for (int i = 0; i < total; ++i) {
-            take(); load(S1{}); step();
-            take(); load(S2{}); step();
-            take();
-            if (++lc == nchunks) { lc = 0; if (lr < r_hi) ++lr; }    // past the end: a valid pair again, never used
-            load(S0{});
-            step();
-        }
     }
 
-    float* yn = y + (int64_t)n * K * Ho * Wo;
-    const bool vec = px0 + 1 < Wo && (((uintptr_t)yn | (uintptr_t)(Wo * 4)) & 7) == 0;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int k = kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-            if (k >= K || px0 >= Wo) continue;
-            const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift ? ep.shift[k] : 0.0f;
-            float o0 = fmaf(acc[kt][0][e], sc, sh), o1 = fmaf(acc[kt][1][e], sc, sh);
-            if (ep.relu) { o0 = fmaxf(o0, 0.0f); o1 = fmaxf(o1, 0.0f); }
-            float* q = yn + ((int64_t)k * Ho + py) * Wo + px0;
-            if (vec) {
-                *reinterpret_cast<float2*>(q) = make_float2(o0, o1);
-            } else {
-                q[0] = o0;
-                if (px0 + 1 < Wo) q[1] = o1;
-            }
-        }
+    store_tiles<KT>(acc, y + (int64_t)n * K * Ho * Wo, ep, kb, kk, K, Ho, Wo, py, px0);
 }
 
 }  // namespace
@@ -189,12 +289,23 @@ static int launch_s2(const char* name, const float* x, const float* arranged, fl
     hipStream_t st = vo_stream(stream);
     const int rem = K % KB;
     const int full = (rem >= 1 && rem <= 32) ? kblocks - 1 : kblocks;         // a last block of <= 32 channels: one k-tile
-    if (full > 0)
-        conv3s2_kernel<2, ONE_TAP><<<dim3((unsigned)(blocks * full)), dim3(256), 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx,
-                                                                                          by, full, 0);
-    if (full < kblocks)
-        conv3s2_kernel<1, ONE_TAP><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx, by, 1,
-                                                                                 full);
+    const dim3 gfull((unsigned)(blocks * (full > 0 ? full : 1))), ghalf((unsigned)blocks), nt(256);
+    const bool pair = W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+#define VO_S2_LAUNCH(KERNEL)                                                                                          \
+    do {                                                                                                              \
+        if (full > 0) KERNEL(2)<<<gfull, nt, 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx, by, full, 0);       \
+        if (full < kblocks) KERNEL(1)<<<ghalf, nt, 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx, by, 1, full); \
+    } while (0)
+#define VO_S2_ONE(KT) conv1s2_kernel<KT>
+#define VO_S2_PAIR(KT) conv3s2_kernel<KT, true>
+#define VO_S2_SINGLE(KT) conv3s2_kernel<KT, false>
+    if (ONE_TAP) VO_S2_LAUNCH(VO_S2_ONE);
+    else if (pair) VO_S2_LAUNCH(VO_S2_PAIR);
+    else VO_S2_LAUNCH(VO_S2_SINGLE);
+#undef VO_S2_LAUNCH
+#undef VO_S2_ONE
+#undef VO_S2_PAIR
+#undef VO_S2_SINGLE
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;

@@ -5,11 +5,14 @@
 // The reduction index is ordered (c, r, s) with s padded from 7 to 8, so one 16-byte load of the
 // pre-arranged weights is the A operand of the four k-steps of one filter row (k-step ks holds the
 // taps s = 2ks and 2ks+1).  A wave owns 64 output channels x 64 consecutive pixels of one image row
-// (pixel tile t = pixels 2n+t, 64 accumulator registers); its B operand for tap s is the input row
-// shifted by s-3, read straight from memory (the 49-fold reuse lives in L1/L2).  Columns outside the
+// (pixel tile t = pixels 32t..32t+31, 64 accumulator registers: neighbouring lanes read neighbouring
+// input pixels, so a load touches as few cache lines as the stride allows); its B operand for tap s is
+// the input row shifted by s-3, read straight from memory (the 49-fold reuse lives in L1/L2).  Columns outside the
 // image get a lane offset past the buffer's extent (the range check returns 0.0f); rows outside
 // the image are skipped altogether.  The four waves of a workgroup take four consecutive rows.
 #include "vo_common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void conv7_kernel(const float* __restrict__ x,
     const int py = by * 4 + wave;                                // this wave's output row
     if (py >= Ho) return;                                        // waves are independent: no barrier anywhere
     const int kk = lane >> 5, nn = lane & 31;
-    const int px0 = bx * 64 + 2 * nn;                            // this lane's first output pixel of the row
+    const int px0 = bx * 64 + nn;                                // this lane's output pixels of the row: px0 and px0 + 32
     const int ncr = C * 7;
 
     const __amdgpu_buffer_rsrc_t xrs =
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void conv7_kernel(const float* __restrict__ x,
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int col = S * (px0 + t) + 2 * ks + kk - 3;
+            const int col = S * (px0 + 32 * t) + 2 * ks + kk - 3;
             coff[ks][t] = (col >= 0 && col < W) ? col * 4 : OOB;
         }
     const int w_off = lane * 16;
@@ -71,57 +74,82 @@ __global__ __launch_bounds__(256) void conv7_kernel(const float* __restrict__ x,
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.0f;
 
-    float bcur[4][2], bnxt[4][2];
-    u32x4 acur[2], anxt[2];
     // the (channel, filter row) pairs whose input row lies inside the image, in order
     const int iy = S * py - 3;                                   // input row of filter row 0
     const int r_lo = iy < 0 ? -iy : 0, r_hi = iy + 6 >= H ? H - 1 - iy : 6;         // valid filter rows r_lo..r_hi
-    const int nr = r_hi - r_lo + 1, total = C * nr;
-    auto load = [&](int i) {
-        i = i < total ? i : total - 1;                           // past the end: reload the last one, never used
-        const int c = i / nr, r = r_lo + i - c * nr;
-        const int cr = c * 7 + r;
-        const int row = ((c * H + iy + r) * W) * 4;              // wave-uniform
+    const int total = C * (r_hi - r_lo + 1);                     // at most 8 * 7
+    // Three operand buffers in rotation: the loads of pair i+3 are issued right after the
+    // multiplications of pair i, so every load has two pairs' worth of matrix instructions (of this wave
+    // alone) to arrive.  The fences keep that issue order, so each wait covers one buffer's ten loads.
+    // The loop body has no branch (the waits stay exact and the accumulators stay in place): the
+    // number of pairs is rounded up to a multiple of three, and a pair past the end reads its weights
+    // from past the buffer's extent, i.e. multiplies by zero.
+    float b[3][4][2];
+    u32x4 a[3][2];
+    const int nr = r_hi - r_lo + 1;
+    const int inv_nr = (65536 + nr - 1) / nr;                    // i / nr == (i * inv_nr) >> 16 for the i < 56 that occur
+    int issued = 0;                                              // pairs whose loads have been issued
+    auto load = [&](auto btag) {
+        constexpr int lb = decltype(btag)::value;
+        // wave-uniform, said explicitly so that no load is wrapped in a loop over lanes
+        const int ii = min(issued, total - 1);                   // past the end: the last pair's input again
+        const int lc = (ii * inv_nr) >> 16, lr = r_lo + ii - lc * nr;      // branch-free on purpose (see above)
+        const int woff = __builtin_amdgcn_readfirstlane((lc * 7 + lr) * 2048);
+        const int row = __builtin_amdgcn_readfirstlane(((lc * H + iy + lr) * W) * 4);
+        const int wv = issued < total ? w_off : OOB;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) anxt[kt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_off + kt * 1024, cr * 2048, 0);
+        for (int kt = 0; kt < 2; ++kt) a[lb][kt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wv + kt * 1024, woff, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                bnxt[ks][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[ks][t] + row, 0, 0));
+                b[lb][ks][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[ks][t], row, 0));
+        ++issued;
+        __builtin_amdgcn_sched_barrier(0);
     };
-    load(0);
-    for (int i = 0; i < total; ++i) {
-        acur[0] = anxt[0]; acur[1] = anxt[1];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { bcur[ks][0] = bnxt[ks][0]; bcur[ks][1] = bnxt[ks][1]; }
-        load(i + 1);
+    auto step = [&](auto btag) {
+        constexpr int lb = decltype(btag)::value;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
-                    acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(acur[kt][ks]), bcur[ks][t], acc[kt][t], 0, 0, 0);
+                    acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[lb][kt][ks]), b[lb][ks][t], acc[kt][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    load(B0{}); load(B1{}); load(B2{});
+    // The compiler interleaves these first thirty loads and would then make every pass of the loop wait
+    // as if they were still in that order.  Naming all their registers here makes it wait for them
+    // once, before the loop; with nothing outstanding at the loop's entry the waits inside follow the
+    // loop's own order (the oldest ten loads before each step).
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        asm volatile("" : "+v"(a[q][0]), "+v"(a[q][1]), "+v"(b[q][0][0]), "+v"(b[q][0][1]), "+v"(b[q][1][0]), "+v"(b[q][1][1]),
+                          "+v"(b[q][2][0]), "+v"(b[q][2][1]), "+v"(b[q][3][0]), "+v"(b[q][3][1]));
+    for (int i = 0; i < total; i += 3) {
+        step(B0{}); load(B0{});
+        step(B1{}); load(B1{});
+        step(B2{}); load(B2{});
     }
 
     float* yn = y + (int64_t)n * K * Ho * Wo;
-    const bool vec = px0 + 1 < Wo && (((uintptr_t)yn | (uintptr_t)(Wo * 4)) & 7) == 0;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int k = kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-            if (k >= K || px0 >= Wo) continue;
+            if (k >= K) continue;
             const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift ? ep.shift[k] : 0.0f;
-            float o0 = fmaf(acc[kt][0][e], sc, sh), o1 = fmaf(acc[kt][1][e], sc, sh);
-            if (ep.relu) { o0 = fmaxf(o0, 0.0f); o1 = fmaxf(o1, 0.0f); }
             float* q = yn + ((int64_t)k * Ho + py) * Wo + px0;
-            if (vec) {
-                *reinterpret_cast<float2*>(q) = make_float2(o0, o1);
-            } else {
-                q[0] = o0;
-                if (px0 + 1 < Wo) q[1] = o1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float o = fmaf(acc[kt][t][e], sc, sh);
+                if (ep.relu) o = fmaxf(o, 0.0f);
+                if (px0 + 32 * t < Wo) q[32 * t] = o;
             }
         }
 }
