@@ -43,4 +43,16 @@ for (N, C, H, W, K) in shapes:
     e0 = (F.conv2d(x, w, None, 1, 1).double() - want).abs().max().item() / scale
     t2, t4 = timeit(lambda: ops.conv3x3_winograd(x, U, K)), timeit(run4)
     gf = 2 * N * K * H * W * C * 9 / 1e9
+    if N >= 16:                                                  # the fused epilogues: bias + ReLU, and the residual join on top
+        b = torch.randn(K, device="cuda"); sk = torch.randn(N, K, H, W, device="cuda")
+        def run_b():
+            assert lib.vo_conv3x3_winograd4(x.data_ptr(), U4.data_ptr(), y.data_ptr(), 0, None, b.data_ptr(), 1, None, None, None,
+                                            0.0, N, C, H, W, K, s) == 0
+        def run_s():
+            assert lib.vo_conv3x3_winograd4(x.data_ptr(), U4.data_ptr(), y.data_ptr(), 0, None, b.data_ptr(), 1, sk.data_ptr(), None,
+                                            None, 0.0, N, C, H, W, K, s) == 0
+        run_s()
+        ref = torch.relu(sk + torch.relu(F.conv2d(x, w, b, 1, 1)))
+        es = (y - ref).abs().max().item() / scale
+        print(f"      bias+relu {timeit(run_b):7.3f} ms   bias+relu+skip {timeit(run_s):7.3f} ms (err {es:.1e})", flush=True)
     print(f"N{N:3d} {C:3d}->{K:3d} @{H}x{W}: err f4 {e4:.1e} f2 {e2:.1e} miopen {e0:.1e} | f2 {t2:7.3f} ms ({gf/t2:6.1f})  f4 {t4:7.3f} ms ({gf/t4:6.1f})  x{t2/t4:.2f}", flush=True)

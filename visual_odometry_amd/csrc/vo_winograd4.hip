@@ -307,15 +307,48 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
             }
     };
     constexpr int rounds = HALF ? 2 : 4;
+    // Everything the stores need from memory is requested ahead of time: the wait counter of vector
+    // memory operations counts loads and stores in one order, so a load issued after a round's stores
+    // could only be waited for together with those stores (a write round trip per round).  Scale and
+    // shift of all rounds are loaded before the first store, the residual input of round q+1 at the top
+    // of round q.
+    const int tile = tid & 31, kq = (tid >> 5) & 15;
+    const int oy = by * 16 + 4 * (tile >> 3), ox = bx * 32 + 4 * (tile & 7);
+    const bool inside = quad_store && oy + 3 < H && ox < W;      // whole tile inside the image, rows 16-byte aligned
+    float scq[rounds], shq[rounds];
+#pragma unroll
+    for (int q = 0; q < rounds; ++q) {
+        const int k = kb * KB + q * 16 + kq;
+        scq[q] = 1.0f; shq[q] = 0.0f;
+        if (ep.shift && k < K) { scq[q] = ep.scale ? ep.scale[k] : 1.0f; shq[q] = ep.shift[k]; }
+    }
+    u32x4 skq[2][4];
+    auto load_skip = [&](auto qtag) {
+        constexpr int q = decltype(qtag)::value;
+        const int k = kb * KB + q * 16 + kq;
+        if (ep.skip && tid < 512 && inside && k < K) {
+            const int voff = ((k * H + oy) * W + ox) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) skq[q & 1][r] = __builtin_amdgcn_raw_buffer_load_b128(srs, voff + r * W * 4, 0, 0);
+        }
+    };
+    load_skip(X0{});
     put_m(0);
     __syncthreads();
+    using X3 = std::integral_constant<int, 3>;
 #pragma unroll
     for (int q = 0; q < rounds; ++q) {
         if (q + 1 < rounds) put_m(q + 1);
+        if (q == 0 && rounds > 1) load_skip(X1{});
+        if (q == 1 && rounds > 2) load_skip(X2{});
+        if (q == 2 && rounds > 3) load_skip(X3{});
         if (tid < 512) {
-            const int tile = tid & 31, kq = tid >> 5;
             const int k = kb * KB + q * 16 + kq;
+            const float sc = scq[q], sh = shq[q];
+            const u32x4 (&sk)[4] = skq[q & 1];
             const float* mp = lds + (q & 1) * M_FLOATS + tile * 16 + 4 * ((kq >> 2) ^ ((tile >> 2) & 3)) + (kq & 3);
+            const bool fast = inside && k < K;
+            const int voff = ((k * H + oy) * W + ox) * 4;
             float s[6][4];                                       // A^T m, column by column
 #pragma unroll
             for (int b = 0; b < 6; ++b)
@@ -324,7 +357,6 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
             float o[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) out_1d(s[0][r], s[1][r], s[2][r], s[3][r], s[4][r], s[5][r], o[r]);
-            const int oy = by * 16 + 4 * (tile >> 3), ox = bx * 32 + 4 * (tile & 7);
             if (ep.stats) {
                 float ps = 0.0f, pq = 0.0f;
 #pragma unroll
@@ -340,11 +372,9 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
                     atomicAdd(st + 1, (double)pq);
                 }
             }
-            if (quad_store && k < K && oy + 3 < H && ox < W) {
-                // whole tile inside the image, rows 16-byte aligned: straight-line code, 16-byte accesses
-                const int voff = ((k * H + oy) * W + ox) * 4;
+            if (fast) {
+                // straight-line code, 16-byte accesses
                 if (ep.shift) {
-                    const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift[k];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -357,9 +387,6 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
                         for (int c = 0; c < 4; ++c) o[r][c] = fmaxf(o[r][c], 0.0f);
                 }
                 if (ep.skip) {
-                    u32x4 sk[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sk[r] = __builtin_amdgcn_raw_buffer_load_b128(srs, voff + r * W * 4, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -376,7 +403,6 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
                 const int64_t off = ((int64_t)k * H + oy) * W + ox;
                 float* p = yn + off;
                 if (ep.shift) {
-                    const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift[k];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
