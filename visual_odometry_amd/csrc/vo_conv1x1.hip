@@ -39,7 +39,7 @@ struct Epi { const float* scale; const float* shift; int relu; int64_t y_batch_s
 
 // KT k-tiles of 32 channels and NTL pixel tiles of 32 pixels per wave (64 or 128 accumulator registers).
 template <int KT, int NTL>
-__global__ __launch_bounds__(256, KT * NTL > 4 ? 2 : 1) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
+__global__ __launch_bounds__(256, 3) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                       float* __restrict__ y, Epi ep, int C, int P, int K, int pblocks,
                                                       int kblocks) {
     constexpr int PW = 32 * NTL;                                 // pixels per wave
@@ -107,19 +107,38 @@ __global__ __launch_bounds__(256, KT * NTL > 4 ? 2 : 1) void conv1x1_kernel(cons
                     acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(acur[kt][ks]), bcur[ks][t], acc[kt][t], 0, 0, 0);
     }
 
+    // All scale and shift values are loaded before the first store: the wait counter of vector memory
+    // operations counts loads and stores in one order, so a load issued between stores could only be
+    // waited for together with the stores before it.  Channels past K read as 0 and are not stored.
     float* yn = y + (int64_t)n * ep.y_batch_stride;
+    float sc[KT][16], sh[KT][16];
+    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.scale), 0, ep.scale ? K * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.shift), 0, ep.shift ? K * 4 : 0, 0x00020000);
+    auto load_affine = [&](int kt, int e0, int count) {
+#pragma unroll
+        for (int e = e0; e < e0 + count; ++e) {
+            const int off = (kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * 4;
+            sc[kt][e] = ep.scale ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(scr, off, 0, 0)) : 1.0f;
+            sh[kt][e] = ep.shift ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(shr, off, 0, 0)) : 0.0f;
+        }
+    };
+    constexpr bool ALL_FIRST = KT * NTL <= 4;                    // with 128 accumulators there is room for 8 channels' values only
+    if (ALL_FIRST) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) load_affine(kt, 0, 16);
+    }
     const bool vec = p0 + NTL <= P && ((reinterpret_cast<uintptr_t>(yn) | (uintptr_t)((int64_t)P * 4) | (uintptr_t)(p0 * 4)) & (NTL * 4 - 1)) == 0;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+    for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
+            if (!ALL_FIRST && (e & 7) == 0) load_affine(kt, e, 8);
             const int k = kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
             if (k >= K || p0 >= P) continue;
-            const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift ? ep.shift[k] : 0.0f;
             float o[NTL];
 #pragma unroll
             for (int t = 0; t < NTL; ++t) {
-                o[t] = fmaf(acc[kt][t][e], sc, sh);
+                o[t] = fmaf(acc[kt][t][e], sc[kt][e], sh[kt][e]);
                 if (ep.relu) o[t] = fmaxf(o[t], 0.0f);
             }
             float* q = yn + (int64_t)k * P + p0;
@@ -132,6 +151,7 @@ __global__ __launch_bounds__(256, KT * NTL > 4 ? 2 : 1) void conv1x1_kernel(cons
                     if (p0 + t < P) q[t] = o[t];
             }
         }
+    }
 }
 
 }  // namespace

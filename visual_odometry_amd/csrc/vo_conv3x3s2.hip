@@ -41,21 +41,35 @@ __global__ __launch_bounds__(256) void filter3s2_kernel(const float* __restrict_
 
 struct Epi { const float* scale; const float* shift; int relu; };
 
-// scale / shift / ReLU and store of a wave's accumulators: lane holds the pixels px0 and px0 + 32 of row py
+// scale / shift / ReLU and store of a wave's accumulators: lane holds the pixels px0 and px0 + 32 of row py.
+// All scale and shift values are loaded before the first store: the wait counter of vector memory
+// operations counts loads and stores in one order, so a load issued between stores could only be
+// waited for together with the stores before it (a write round trip per channel).  Channels past K
+// read as 0 through the range check and are not stored.
 template <int KT>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[KT][2], float* __restrict__ yn, const Epi& ep, int kb, int kk,
                                             int K, int Ho, int Wo, int py, int px0) {
+    float sc[KT][16], sh[KT][16];
+    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.scale), 0, ep.scale ? K * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.shift), 0, ep.shift ? K * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int off = (kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * 4;
+            sc[kt][e] = ep.scale ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(scr, off, 0, 0)) : 1.0f;
+            sh[kt][e] = ep.shift ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(shr, off, 0, 0)) : 0.0f;
+        }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int k = kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
             if (k >= K) continue;
-            const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift ? ep.shift[k] : 0.0f;
             float* q = yn + ((int64_t)k * Ho + py) * Wo + px0;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                float o = fmaf(acc[kt][t][e], sc, sh);
+                float o = fmaf(acc[kt][t][e], sc[kt][e], sh[kt][e]);
                 if (ep.relu) o = fmaxf(o, 0.0f);
                 if (px0 + 32 * t < Wo) q[32 * t] = o;
             }
@@ -65,7 +79,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[KT][2], float* _
 // KT: k-tiles of 32 output channels per wave (1 for a last block with at most 32 channels).
 // PAIR: the width is even and x is 8-byte aligned, so the columns 2px and 2px+1 come with one load.
 template <int KT, bool PAIR>
-__global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
+__global__ __launch_bounds__(256, 3) void conv3s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                       float* __restrict__ y, Epi ep, int C, int H, int W, int Ho, int Wo, int K,
                                                       int blocks_x, int blocks_y, int kblocks, int kb_base) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(256) void conv3s2_kernel(const float* __restrict__ 
 // centre one) and the reduction over chunks of 8 input channels; the weights are in
 // vo_conv1x1_filter's order, Wg[kb][chunk][kt][lane][ks] with c = chunk*8 + 2*ks + (lane >> 5).
 template <int KT>
-__global__ __launch_bounds__(256) void conv1s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
+__global__ __launch_bounds__(256, 3) void conv1s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                       float* __restrict__ y, Epi ep, int C, int H, int W, int Ho, int Wo, int K,
                                                       int blocks_x, int blocks_y, int kblocks, int kb_base) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -36,7 +36,7 @@ struct Epi { const float* scale; const float* shift; int relu; };
 
 // S: stride.  (H, W): input size, (Ho, Wo): output size.
 template <int S>
-__global__ __launch_bounds__(256) void conv7_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
+__global__ __launch_bounds__(256, 3) void conv7_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                     float* __restrict__ y, Epi ep, int C, int H, int W, int Ho, int Wo, int K,
                                                     int blocks_x, int blocks_y, int kblocks) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -136,18 +136,31 @@ __global__ __launch_bounds__(256) void conv7_kernel(const float* __restrict__ x,
         step(B2{}); load(B2{});
     }
 
+    // All scale and shift values are loaded before the first store: the wait counter of vector memory
+    // operations counts loads and stores in one order, so a load issued between stores could only be
+    // waited for together with the stores before it.  Channels past K read as 0 and are not stored.
     float* yn = y + (int64_t)n * K * Ho * Wo;
+    float sc[2][16], sh[2][16];
+    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.scale), 0, ep.scale ? K * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep.shift), 0, ep.shift ? K * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int off = (kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * 4;
+            sc[kt][e] = ep.scale ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(scr, off, 0, 0)) : 1.0f;
+            sh[kt][e] = ep.shift ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(shr, off, 0, 0)) : 0.0f;
+        }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int k = kb * KB + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
             if (k >= K) continue;
-            const float sc = ep.scale ? ep.scale[k] : 1.0f, sh = ep.shift ? ep.shift[k] : 0.0f;
             float* q = yn + ((int64_t)k * Ho + py) * Wo + px0;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                float o = fmaf(acc[kt][t][e], sc, sh);
+                float o = fmaf(acc[kt][t][e], sc[kt][e], sh[kt][e]);
                 if (ep.relu) o = fmaxf(o, 0.0f);
                 if (px0 + 32 * t < Wo) q[32 * t] = o;
             }
