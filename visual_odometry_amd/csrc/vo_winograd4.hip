@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     float* raw = lds + 2 * V_FLOATS;
     float2* nrm = reinterpret_cast<float2*>(lds + LDS_FLOATS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: scalar
     int bid;
     {   // one contiguous range of the block list per XCD (workgroups are dealt round robin over 8)
         const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
@@ -293,7 +293,9 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yn, 0, K * H * W * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(ep.skip ? ep.skip + (int64_t)n * K * H * W : x), 0, ep.skip ? K * H * W * 4 : 0, 0x00020000);
-    const int kk = lane >> 5, nn = lane & 31;
+    // the lane index is recomputed here (it costs nothing) instead of being kept alive through the main loop
+    const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int kk = elane >> 5, nn = elane & 31;
     auto put_m = [&](int q) {
         float* mb = lds + (q & 1) * M_FLOATS + (3 * wave) * 512 + nn * 16;
 #pragma unroll
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     // could only be waited for together with those stores (a write round trip per round).  Scale and
     // shift of all rounds are loaded before the first store, the residual input of round q+1 at the top
     // of round q.
-    const int tile = tid & 31, kq = (tid >> 5) & 15;
+    const int tile = elane & 31, kq = (2 * wave + (elane >> 5)) & 15;
     const int oy = by * 16 + 4 * (tile >> 3), ox = bx * 32 + 4 * (tile & 7);
     const bool inside = quad_store && oy + 3 < H && ox < W;      // whole tile inside the image, rows 16-byte aligned
     float scq[rounds], shq[rounds];
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     auto load_skip = [&](auto qtag) {
         constexpr int q = decltype(qtag)::value;
         const int k = kb * KB + q * 16 + kq;
-        if (ep.skip && tid < 512 && inside && k < K) {
+        if (ep.skip && wave < 8 && inside && k < K) {
             const int voff = ((k * H + oy) * W + ox) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) skq[q & 1][r] = __builtin_amdgcn_raw_buffer_load_b128(srs, voff + r * W * 4, 0, 0);
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
         if (q == 0 && rounds > 1) load_skip(X1{});
         if (q == 1 && rounds > 2) load_skip(X2{});
         if (q == 2 && rounds > 3) load_skip(X3{});
-        if (tid < 512) {
+        if (wave < 8) {
             const int k = kb * KB + q * 16 + kq;
             const float sc = scq[q], sh = shq[q];
             const u32x4 (&sk)[4] = skq[q & 1];
