@@ -27,8 +27,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CB = 8;                      // input channels per chunk
 constexpr int KB = 64;                     // output channels per workgroup
 constexpr int NT = 768;                    // threads per workgroup
-constexpr int PR = 18, PC = 34;            // raw patch of 4x8 tiles of 4x4 pixels plus the halo
-constexpr int RAW_C = PR * PC;             // 612 floats per channel, stored without padding
+constexpr int RAW_C = 18 * 34;             // raw patch of 4x8 (or 8x4) tiles of 4x4 pixels plus the halo: 612 floats per channel, no padding
 constexpr int RAW_FLOATS = CB * RAW_C;     // 4896
 constexpr int RAW_PER_LANE = (RAW_FLOATS + NT - 1) / NT;     // 7
 constexpr int V_XI = CB * 32;              // floats per position: [kk][tile][ks], c = 2*ks + kk
@@ -105,9 +104,11 @@ __device__ __forceinline__ void out_1d(float m0, float m1, float m2, float m3, f
     o[3] = fmaf(8.0f, s, q) + m5;
 }
 
+// TALL: the workgroup's 32 tiles are 8 rows x 4 columns (32x16 pixels) instead of 4 x 8 (16x32 pixels); the
+// host picks whichever wastes less of the map (80 pixels of width are 5 blocks of 16 but 3 of 32).
 // HALF: the launch covers one block of output channels of which only the lower 32 exist (K mod 64
 // in 1..32): the upper k-tile's matrix instructions, filter loads and output rounds are left out.
-template <bool NORM_IN, bool HALF>
+template <bool NORM_IN, bool HALF, bool TALL>
 __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                    float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H, int W,
                                                    int K, int blocks_x, int blocks_y, int kblocks, int kb_base) {
@@ -118,6 +119,9 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     float* raw = lds + 2 * V_FLOATS;
     float2* nrm = reinterpret_cast<float2*>(lds + LDS_FLOATS);
 
+    constexpr int TX = TALL ? 4 : 8;                             // tile columns of the block; tile t is at (t / TX, t % TX)
+    constexpr int BH = TALL ? 32 : 16, BW = TALL ? 16 : 32;      // block size in pixels
+    constexpr int PC = BW + 2;                                   // columns of the raw patch
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: scalar
     int bid;
     {   // one contiguous range of the block list per XCD (workgroups are dealt round robin over 8)
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     const int by = bid % blocks_y;
     const int n = bid / blocks_y;
     const int nchunks = C / CB;
-    const int y0 = by * 16 - 1, x0 = bx * 32 - 1;
+    const int y0 = by * BH - 1, x0 = bx * BW - 1;
     const float* xn = x + (int64_t)n * C * H * W;
 
     // Buffer descriptors.  Lanes of the zero padding carry an offset past the extent, which the
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     // tiles 16*(v >> 1) .. +15; lane: ks = lane & 3, tile = 16*(v >> 1) + (lane >> 2); c = 2*ks + kk
     const int tg = wave >> 2, tv = wave & 3;
     const int t_kk = tv & 1, t_tile = (tv >> 1) * 16 + (lane >> 2), t_c = 2 * (lane & 3) + t_kk;
-    const int t_raw = t_c * RAW_C + (4 * (t_tile >> 3)) * PC + 4 * (t_tile & 7);
+    const int t_raw = t_c * RAW_C + (4 * (t_tile / TX)) * PC + 4 * (t_tile % TX);
     const int t_v = t_kk * 128 + (tv >> 1) * 64 + lane;          // + xi * V_XI
     auto transform_g = [&](int buf, auto gtag) {
         constexpr int G = decltype(gtag)::value;
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(NT) void wino4_kernel(const float* __restrict__ x, 
     // shift of all rounds are loaded before the first store, the residual input of round q+1 at the top
     // of round q.
     const int tile = elane & 31, kq = (2 * wave + (elane >> 5)) & 15;
-    const int oy = by * 16 + 4 * (tile >> 3), ox = bx * 32 + 4 * (tile & 7);
+    const int oy = by * BH + 4 * (tile / TX), ox = bx * BW + 4 * (tile % TX);
     const bool inside = quad_store && oy + 3 < H && ox < W;      // whole tile inside the image, rows 16-byte aligned
     float scq[rounds], shq[rounds];
 #pragma unroll
@@ -463,7 +467,10 @@ extern "C" int vo_conv3x3_winograd4(const float* x, const float* transformed, fl
         return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: one image of the input or output exceeds 2 GiB");
     if (in_stats && C > MAX_NORM_C)
         return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: normalise-on-load supports at most %d input channels", MAX_NORM_C);
-    const int bx = (W + 31) / 32, by = (H + 15) / 16;
+    // block shape: 16x32 pixels, or 32x16 where that covers the map with less waste
+    const int64_t wide_px = (int64_t)((W + 31) / 32 * 32) * ((H + 15) / 16 * 16), tall_px = (int64_t)((W + 15) / 16 * 16) * ((H + 31) / 32 * 32);
+    const bool tall = tall_px < wide_px;
+    const int bx = tall ? (W + 15) / 16 : (W + 31) / 32, by = tall ? (H + 31) / 32 : (H + 15) / 16;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_winograd4: grid too large");
@@ -473,16 +480,23 @@ extern "C" int vo_conv3x3_winograd4(const float* x, const float* transformed, fl
     const int rem = K % KB;
     const int full = (rem >= 1 && rem <= 32) ? kblocks - 1 : kblocks;
     hipStream_t st = vo_stream(stream);
-    if (full > 0) {
-        const dim3 grid((unsigned)(blocks * full));
-        if (in_stats) wino4_kernel<true, false><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, full, 0);
-        else wino4_kernel<false, false><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, full, 0);
-    }
-    if (full < kblocks) {
-        const dim3 grid((unsigned)blocks);
-        if (in_stats) wino4_kernel<true, true><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, 1, full);
-        else wino4_kernel<false, true><<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, 1, full);
-    }
+    auto launch = [&](auto shape) {
+        constexpr bool TALL = decltype(shape)::value;
+#define W4(NORM, HALF) wino4_kernel<NORM, HALF, TALL>
+        if (full > 0) {
+            const dim3 grid((unsigned)(blocks * full));
+            if (in_stats) W4(true, false)<<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, full, 0);
+            else W4(false, false)<<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, full, 0);
+        }
+        if (full < kblocks) {
+            const dim3 grid((unsigned)blocks);
+            if (in_stats) W4(true, true)<<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, 1, full);
+            else W4(false, true)<<<grid, dim3(NT), 0, st>>>(x, transformed, y, ep, nrm, C, H, W, K, bx, by, 1, full);
+        }
+#undef W4
+    };
+    if (tall) launch(std::true_type{});
+    else launch(std::false_type{});
     VO_CHECK_LAUNCH("vo_conv3x3_winograd4");
     return VO_OK;
 }
