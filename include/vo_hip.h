@@ -157,10 +157,17 @@ int vo_conv5_winograd(const float* x, const float* transformed, float* y, int N,
  *   vo_conv1x1_filter  weight (K,C) -> weights in matrix-operand order, ceil(K/64)*64 * ceil(C/8)*8 floats.
  *   vo_conv1x1         x (N,C,P), P = H*W pixels -> y (N,K,P): v = sum_c W[k,c] x[c,p]; then
  *                      v*scale[k] + shift[k] (either may be NULL) and ReLU when relu != 0.  y may be a
- *                      channel slice of a wider tensor (items y_batch_stride ELEMENTS apart, 0 = dense). */
+ *                      channel slice of a wider tensor (items y_batch_stride ELEMENTS apart, 0 = dense).
+ *   vo_conv1x1_pixel_major  the same convolution with the output written as y (N,P,K): each pixel's K
+ *                      values contiguous, the layout vo_corr_volume_2d / _1d read.  It is the last layer
+ *                      of the feature encoders (core/extractor.py's conv2 in both published models) and
+ *                      replaces their NCHW output plus the permute(0,2,3,1).contiguous() copy in front
+ *                      of the correlation (core/corr.py). */
 int vo_conv1x1_filter(const float* weight, float* arranged, int K, int C, void* stream);
 int vo_conv1x1(const float* x, const float* arranged, float* y, int64_t y_batch_stride, const float* scale,
                const float* shift, int relu, int N, int C, int64_t P, int K, void* stream);
+int vo_conv1x1_pixel_major(const float* x, const float* arranged, float* y, const float* scale, const float* shift,
+                           int relu, int N, int C, int64_t P, int K, void* stream);
 
 /* 7x7 padding-3 float32 convolution (stride 1 or 2) with at most 8 input channels, NCHW, as a
  * streaming matrix-core GEMM (no LDS): the stems of the encoders (3 -> 64 at full resolution,

@@ -661,10 +661,17 @@ def test_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
     ops.conv1x1(x, Wg, K, None, shift, True, out=wide[:, 3:3 + K])
     assert (wide[:, 3:3 + K].double() - torch.relu(ref + b(shift))).abs().max().item() < tol
     assert torch.all(wide[:, :3] == 7.5) and torch.all(wide[:, 3 + K:] == 7.5)
+    # the pixel-major output is the same numbers in (N,H,W,K) order, bit for bit
+    pm = ops.conv1x1_pixel_major(x, Wg, K, scale, shift, False)
+    assert pm.shape == (N, H, W, K) and pm.is_contiguous()
+    assert torch.equal(pm, got.permute(0, 2, 3, 1))
+    assert torch.equal(ops.conv1x1_pixel_major(x, Wg, K, None, shift, True), ops.conv1x1(x, Wg, K, None, shift, True).permute(0, 2, 3, 1))
     with pytest.raises(ValueError):
         ops.conv1x1(x, Wg[:-1].contiguous(), K)
     with pytest.raises(ValueError):
         ops.conv1x1(x, Wg, K, None, shift[:-1].contiguous())
+    with pytest.raises(ValueError):
+        ops.conv1x1_pixel_major(x, Wg[:-1].contiguous(), K)
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(1, 3, 5, 7, 64), (2, 2, 33, 70, 40), (2, 3, 9, 130, 100), (1, 1, 2, 3, 5),

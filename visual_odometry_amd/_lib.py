@@ -34,6 +34,7 @@ SIGNATURES = {
     "vo_conv5_winograd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_filter": [_P, _P, _I, _I, _P],
     "vo_conv1x1": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _L, _I, _P],
+    "vo_conv1x1_pixel_major": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     "vo_conv7x7_filter": [_P, _P, _I, _I, _P],
     "vo_conv7x7": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv3x3s2_filter": [_P, _P, _I, _I, _P],

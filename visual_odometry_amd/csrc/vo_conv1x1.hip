@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void filter1x1_kernel(const float* __restrict_
 struct Epi { const float* scale; const float* shift; int relu; int64_t y_batch_stride; };
 
 // KT k-tiles of 32 channels and NTL pixel tiles of 32 pixels per wave (64 or 128 accumulator registers).
-template <int KT, int NTL>
+// PM: the output is written pixel-major, y[n][p][k] (each pixel's K values contiguous: the layout the
+// correlation kernels read), four consecutive channels per 16-byte store.
+template <int KT, int NTL, bool PM>
 __global__ __launch_bounds__(256, 3) void conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                       float* __restrict__ y, Epi ep, int C, int P, int K, int pblocks,
                                                       int kblocks) {
@@ -127,6 +129,39 @@ __global__ __launch_bounds__(256, 3) void conv1x1_kernel(const float* __restrict
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) load_affine(kt, 0, 16);
     }
+    if (PM) {
+        // a lane's elements e..e+3 are the channels k0..k0+3 of its pixels
+        float* yp = y + (int64_t)n * P * K;
+        const bool quad = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (!ALL_FIRST && (g & 1) == 0) load_affine(kt, 4 * g, 8);
+                const int k0 = kb * KB + kt * 32 + 8 * g + 4 * kk;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    const int p = p0 + t;
+                    if (p >= P || k0 >= K) continue;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = fmaf(acc[kt][t][4 * g + j], sc[kt][4 * g + j], sh[kt][4 * g + j]);
+                        if (ep.relu) o[j] = fmaxf(o[j], 0.0f);
+                    }
+                    float* q = yp + (int64_t)p * K + k0;
+                    if (quad) {
+                        *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k0 + j < K) q[j] = o[j];
+                    }
+                }
+            }
+        }
+        return;
+    }
     const bool vec = p0 + NTL <= P && ((reinterpret_cast<uintptr_t>(yn) | (uintptr_t)((int64_t)P * 4) | (uintptr_t)(p0 * 4)) & (NTL * 4 - 1)) == 0;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -166,8 +201,9 @@ extern "C" int vo_conv1x1_filter(const float* weight, float* arranged, int K, in
     return VO_OK;
 }
 
-extern "C" int vo_conv1x1(const float* x, const float* arranged, float* y, int64_t y_batch_stride, const float* scale,
-                          const float* shift, int relu, int N, int C, int64_t P, int K, void* stream) {
+template <bool PM>
+static int launch_1x1(const float* x, const float* arranged, float* y, int64_t y_batch_stride, const float* scale,
+                      const float* shift, int relu, int N, int C, int64_t P, int K, void* stream) {
     VO_REQUIRE(x && arranged && y, "vo_conv1x1: null pointer");
     VO_REQUIRE(N > 0 && C > 0 && P > 0 && K > 0, "vo_conv1x1: bad sizes");
     VO_REQUIRE(x != y, "vo_conv1x1: the output must not alias the input");
@@ -181,19 +217,29 @@ extern "C" int vo_conv1x1(const float* x, const float* arranged, float* y, int64
     if (K <= 32) {                                               // one k-tile, 128 pixels per wave
         const int64_t pblocks = vo_ceil_div(P, 4 * 128);
         if (pblocks * N > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv1x1: grid too large");
-        conv1x1_kernel<1, 4><<<dim3((unsigned)(pblocks * N)), dim3(256), 0, st>>>(x, arranged, y, ep, C, (int)P, K, (int)pblocks, 1);
+        conv1x1_kernel<1, 4, PM><<<dim3((unsigned)(pblocks * N)), dim3(256), 0, st>>>(x, arranged, y, ep, C, (int)P, K, (int)pblocks, 1);
     } else {
         const int64_t pblocks = vo_ceil_div(P, 4 * 64);
         if (pblocks * N * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv1x1: grid too large");
         if (C <= 128) {                                          // short reductions: 128 pixels per wave (measured faster)
             const int64_t pb4 = vo_ceil_div(P, 4 * 128);
-            conv1x1_kernel<2, 4><<<dim3((unsigned)(pb4 * N * kblocks)), dim3(256), 0, st>>>(x, arranged, y, ep, C, (int)P, K,
+            conv1x1_kernel<2, 4, PM><<<dim3((unsigned)(pb4 * N * kblocks)), dim3(256), 0, st>>>(x, arranged, y, ep, C, (int)P, K,
                                                                                            (int)pb4, kblocks);
         } else {
-            conv1x1_kernel<2, 2><<<dim3((unsigned)(pblocks * N * kblocks)), dim3(256), 0, st>>>(x, arranged, y, ep, C, (int)P, K,
+            conv1x1_kernel<2, 2, PM><<<dim3((unsigned)(pblocks * N * kblocks)), dim3(256), 0, st>>>(x, arranged, y, ep, C, (int)P, K,
                                                                                                (int)pblocks, kblocks);
         }
     }
     VO_CHECK_LAUNCH("vo_conv1x1");
     return VO_OK;
+}
+
+extern "C" int vo_conv1x1(const float* x, const float* arranged, float* y, int64_t y_batch_stride, const float* scale,
+                          const float* shift, int relu, int N, int C, int64_t P, int K, void* stream) {
+    return launch_1x1<false>(x, arranged, y, y_batch_stride, scale, shift, relu, N, C, P, K, stream);
+}
+
+extern "C" int vo_conv1x1_pixel_major(const float* x, const float* arranged, float* y, const float* scale, const float* shift,
+                                      int relu, int N, int C, int64_t P, int K, void* stream) {
+    return launch_1x1<true>(x, arranged, y, 0, scale, shift, relu, N, C, P, K, stream);
 }

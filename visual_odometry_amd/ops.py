@@ -325,6 +325,24 @@ def conv1x1(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor
     return out
 
 
+def conv1x1_pixel_major(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+                        shift: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
+    """conv1x1 with the output in pixel-major order: x (N,C,H,W) float32 -> (N,H,W,K), i.e.
+    conv2d(x, weight).permute(0, 2, 3, 1).contiguous() without the copy (the layout the correlation
+    kernels read)."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * ((C + 7) // 8 * 8):
+        raise ValueError("arranged weights do not match (K, C)")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    out = torch.empty((N, H, W, K), device=x.device, dtype=torch.float32)
+    _call("vo_conv1x1_pixel_major", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H * W, K, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * N * K * C * H * W)
+    return out
+
+
 def conv7x7_filter(weight: torch.Tensor) -> torch.Tensor:
     """(K,C,7,7) float32 weight, C <= 8 -> the arranged weights conv7x7 consumes."""
     if weight.dim() != 4 or tuple(weight.shape[2:]) != (7, 7) or weight.shape[1] > 8:

@@ -96,6 +96,17 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+def conv_pixel_major(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """conv(x) with bias as float32 (N,H,W,K): each pixel's feature vector contiguous, the layout
+    the correlation kernels read.  A float32 1x1 convolution writes it directly; anything else is
+    the convolution followed by the permuting copy."""
+    if (x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and fused_on() and conv.bias is not None and x.is_cuda):
+        Wg = _conv1x1_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if Wg is not None:
+            return ops.conv1x1_pixel_major(x, Wg, conv.out_channels, None, conv.bias, False)
+    return conv_plain(x, conv).float().permute(0, 2, 3, 1).contiguous()
+
+
 _WINOGRAD = True            # float32 3x3 stride-1 convolutions on the hand-written Winograd/MFMA kernels
 _WINOGRAD_TILE = 0          # 0: pick F(2x2,3x3) or F(4x4,3x3) per layer shape; 2 or 4: force one
 
@@ -115,11 +126,14 @@ def winograd_tile(tile: int) -> None:
 
 
 def _winograd_tile_for(H: int, W: int) -> int:
-    """F(4x4,3x3) does a pixel in about 1/1.55 of F(2x2,3x3)'s time but works on 16x32-pixel
-    blocks instead of 16x16: take it unless the padding of narrow maps eats the gain."""
+    """F(4x4,3x3) does a pixel in about 1/1.55 of F(2x2,3x3)'s time but works on 16x32- or
+    32x16-pixel blocks (whichever covers the map with less padding) instead of 16x16: take it
+    unless the padding of small maps eats the gain."""
     if _WINOGRAD_TILE:
         return _WINOGRAD_TILE
-    return 4 if ((W + 31) // 32) * 2 < 1.55 * ((W + 15) // 16) else 2
+    up = lambda v, m: (v + m - 1) // m * m
+    covered4 = min(up(H, 16) * up(W, 32), up(H, 32) * up(W, 16))
+    return 4 if covered4 < 1.55 * up(H, 16) * up(W, 16) else 2
 
 
 def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
@@ -441,10 +455,11 @@ class BasicEncoder(nn.Module):
         self.in_planes = dim
         return blocks
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pixel_major: bool = False) -> torch.Tensor:
+        """``pixel_major``: return float32 (B,H,W,D) instead of (B,D,H,W)."""
         x = conv_norm_act(x, self.conv1, self.norm1, True)
         x = self.layer3(self.layer2(self.layer1(x)))
-        return conv_plain(x, self.conv2)
+        return conv_pixel_major(x, self.conv2) if pixel_major else conv_plain(x, self.conv2)
 
 
 class MultiBasicEncoder(nn.Module):

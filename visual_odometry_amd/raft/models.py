@@ -83,8 +83,7 @@ class RAFTFlow(nn.Module):
     def features(self, images: torch.Tensor) -> torch.Tensor:
         """Normalised images (B,3,H,W) -> pixel-major feature maps (B,H/8,W/8,256)."""
         with fused_passes():
-            fmap = self.fnet(images.to(self._act_dtype()))
-        return pixel_major(fmap)
+            return self.fnet(images.to(self._act_dtype()), pixel_major=True)
 
     @torch.no_grad()
     def forward(self, image1, image2, iters: int = 12, flow_init=None, fmap1=None, fmap2=None,
@@ -179,13 +178,12 @@ class RAFTStereo(nn.Module):
         with fused_passes():
             image1, image2 = image1.to(act), image2.to(act)
             cnet_list = self.cnet(image1, num_layers=c.n_gru_layers)
-            both = self.fnet(torch.cat([image1, image2], dim=0))
+            both = self.fnet(torch.cat([image1, image2], dim=0), pixel_major=True)
             net_list = [torch.tanh(x[0]) for x in cnet_list]
             inp_list = [torch.relu(x[1]) for x in cnet_list]
             # the GRUs' context terms do not change across iterations: convolve once
             inp_list = [list(conv_plain(i, conv).split(split_size=conv.out_channels // 3, dim=1))
                         for i, conv in zip(inp_list, self.context_zqr_convs)]
-        both = pixel_major(both)
         fmap1, fmap2 = both[:B], both[B:]
 
         corr = ops.corr_volume_1d(fmap1, fmap2)
