@@ -100,6 +100,11 @@ int vo_add_relu(void* a, const void* b, int64_t n, int dtype, void* stream);
  * slice of a wider tensor: items out_batch_stride ELEMENTS apart (0 = dense). */
 int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_stride, int batch, int channels,
                        int h, int w, int H, int W, int dtype, void* stream);
+/* (planes,h,w) -> (planes,(h-1)/2+1,(w-1)/2+1): 3x3 average pooling, stride 2, padding 1, the padding
+ * counted in the divisor (torch's avg_pool2d(x, 3, stride=2, padding=1)): the downward state exchange
+ * (pool2x) of the same multi-level GRU (core/update.py of the RAFT-Stereo model built at
+ * stereo/stereo_disparity_RAFT.py:46).  Both tensors dense. */
+int vo_avg_pool3x3s2(const void* in, void* out, int64_t planes, int h, int w, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * 3x3, stride 1, padding 1 float32 convolution (NCHW, no bias) as Winograd F(2x2,3x3)

@@ -371,6 +371,22 @@ def test_fused_gru_steps_match_stock_operators(vo):
         assert (a[1] - b[1]).abs().max().item() < 1e-3 and (a[2] - b[2]).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 30, 40), (1, 2, 7, 9), (2, 4, 1, 1), (1, 3, 16, 22), (1, 1, 5, 64)])
+def test_avg_pool3x3s2_matches_avg_pool2d(vo, shape):
+    """RAFT-Stereo's pool2x (3x3 / stride 2 / padding 1, padding counted) in float32 and float16
+    storage: even and odd sizes, widths with and without the 16-byte paths."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(*shape, seed=77).to(DEV)
+    want = Fn.avg_pool2d(x.double(), 3, stride=2, padding=1)
+    got = ops.avg_pool3x3s2(x)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < 1e-6
+    got16 = ops.avg_pool3x3s2(x.half())
+    assert got16.dtype == torch.float16
+    assert (got16.double() - Fn.avg_pool2d(x.half().double(), 3, stride=2, padding=1)).abs().max().item() < 2e-3
+
+
 @pytest.mark.parametrize("shape,size", [((2, 5, 6, 10), (12, 20)), ((1, 64, 60, 80), (120, 160)), ((1, 3, 7, 5), (9, 13)),
                                         ((1, 2, 1, 4), (1, 9)), ((2, 3, 8, 8), (8, 8))])
 def test_resize_bilinear_matches_interpolate(vo, shape, size):

@@ -182,6 +182,53 @@ __global__ __launch_bounds__(256) void resize_kernel(const T* __restrict__ in, T
     }
 }
 
+// 3x3 average pooling, stride 2, padding 1, the padding counted in the divisor (torch's
+// avg_pool2d(x, 3, stride=2, padding=1)): RAFT-Stereo's pool2x between GRU levels.
+// One lane per 4 output pixels of a row: 9 input columns of 3 rows.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t total, int h, int w,
+                                                   int H, int W, bool vec) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int wq = (W + 3) >> 2;
+    const int xq = (int)(t % wq);
+    const int y = (int)((t / wq) % H);
+    const int64_t plane = t / ((int64_t)wq * H);
+    const T* p = in + plane * (int64_t)h * w;
+    float col[9];                                                // column sums over the three rows, columns 8xq-1 .. 8xq+7
+#pragma unroll
+    for (int j = 0; j < 9; ++j) col[j] = 0.0f;
+    const int xb = 8 * xq;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = 2 * y + dy;
+        if (yy < 0 || yy >= h) continue;
+        const T* r = p + (int64_t)yy * w;
+        if (xb >= 1) col[0] += vo_ld1(r, xb - 1);
+        if (vec && xb + 8 <= w) {
+            const float4 a = vo_ld4<T>(r + xb, 0), b = vo_ld4<T>(r + xb + 4, 0);
+            col[1] += a.x; col[2] += a.y; col[3] += a.z; col[4] += a.w;
+            col[5] += b.x; col[6] += b.y; col[7] += b.z; col[8] += b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (xb + j < w) col[1 + j] += vo_ld1(r, xb + j);
+        }
+    }
+    T* o = out + (plane * H + y) * (int64_t)W + 4 * xq;
+    const float k = 1.0f / 9.0f;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (col[2 * i] + col[2 * i + 1] + col[2 * i + 2]) * k;
+    if (vec && (W & 3) == 0) {
+        vo_st4<T>(o, 0, make_float4(v[0], v[1], v[2], v[3]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * xq + i < W) vo_st1(o, i, v[i]);
+    }
+}
+
 int check_dtype(const char* fn, int dtype) {
     if (dtype != VO_F32 && dtype != VO_F16) return vo_fail(VO_ERR_INVALID_ARG, "%s: dtype=%d is neither VO_F32 nor VO_F16", fn, dtype);
     return VO_OK;
@@ -210,6 +257,25 @@ extern "C" int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_s
         resize_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((const float*)in, (float*)out, total, channels,
                                                                        out_batch_stride, h, w, H, W, sy, sx, vec);
     VO_CHECK_LAUNCH("vo_resize_bilinear");
+    return VO_OK;
+}
+
+extern "C" int vo_avg_pool3x3s2(const void* in, void* out, int64_t planes, int h, int w, int dtype, void* stream) {
+    VO_REQUIRE(in && out, "vo_avg_pool3x3s2: null pointer");
+    VO_REQUIRE(planes > 0 && h > 0 && w > 0, "vo_avg_pool3x3s2: bad sizes");
+    if (int rc = check_dtype("vo_avg_pool3x3s2", dtype)) return rc;
+    const int H = (h - 1) / 2 + 1, W = (w - 1) / 2 + 1;
+    const int64_t total = planes * H * ((W + 3) / 4);
+    const int64_t blocks = vo_ceil_div(total, 256);
+    if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_avg_pool3x3s2: grid too large");
+    const size_t es = dtype == VO_F16 ? 2 : 4;
+    const bool vec = (w & 3) == 0 && vo_vec4_ok(in, es) && vo_vec4_ok(out, es);     // rows of both tensors 4-element aligned
+    const dim3 grid((unsigned)blocks);
+    if (dtype == VO_F16)
+        pool_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((const __half*)in, (__half*)out, total, h, w, H, W, vec);
+    else
+        pool_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((const float*)in, (float*)out, total, h, w, H, W, vec);
+    VO_CHECK_LAUNCH("vo_avg_pool3x3s2");
     return VO_OK;
 }
 

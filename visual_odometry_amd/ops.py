@@ -204,6 +204,15 @@ def resize_bilinear(x: torch.Tensor, size, out: torch.Tensor | None = None) -> t
     return out
 
 
+def avg_pool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,h,w) -> (B,C,(h-1)//2+1,(w-1)//2+1): avg_pool2d(x, 3, stride=2, padding=1)."""
+    B, C, h, w = x.shape
+    px, dt, es = _act(x, "x")
+    out = torch.empty((B, C, (h - 1) // 2 + 1, (w - 1) // 2 + 1), device=x.device, dtype=x.dtype)
+    _call("vo_avg_pool3x3s2", px, out.data_ptr(), B * C, h, w, dt, _stream(), nbytes=es * (x.numel() + out.numel()))
+    return out
+
+
 def winograd_filter(weight: torch.Tensor, tile: int = 2) -> torch.Tensor:
     """(K,C,3,3) float32 weight -> the transformed filter conv3x3_winograd consumes.
     ``tile`` 2: F(2x2,3x3), 16 positions; 4: F(4x4,3x3), 36 positions (fewer multiplies,

@@ -205,6 +205,8 @@ class BasicUpdateBlock(nn.Module):
 
 
 def pool2x(x):
+    if fused_on() and x.is_cuda and x.dtype in (torch.float32, torch.float16) and x.is_contiguous():
+        return ops.avg_pool3x3s2(x)
     return F.avg_pool2d(x, 3, stride=2, padding=1)
 
 
