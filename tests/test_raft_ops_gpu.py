@@ -718,10 +718,11 @@ def test_conv7x7_matches_the_stock_convolution(vo, N, C, H, W, K, stride):
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(1, 8, 5, 7, 64), (2, 16, 33, 70, 40), (2, 24, 9, 131, 100), (1, 8, 1, 1, 3),
-                                       (2, 64, 48, 256, 96)])
+                                       (2, 64, 48, 256, 96), (1, 16, 20, 320, 96), (2, 8, 31, 160, 64)])
 def test_conv3x3s2_matches_the_stock_convolution(vo, N, C, H, W, K):
     """The streaming MFMA 3x3 stride-2 convolution (encoders' downsampling layers) against the float64
-    convolution: odd and even sizes, a single pixel, partial channel blocks (one k-tile launch);
+    convolution: odd and even sizes, a single pixel, partial channel blocks (one k-tile launch), widths
+    on the two-rows-of-32 variant (160 and 80 pixels out, an odd number of output rows);
     scale / shift / ReLU at the store."""
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops

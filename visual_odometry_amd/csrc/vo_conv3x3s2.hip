@@ -46,7 +46,8 @@ struct Epi { const float* scale; const float* shift; int relu; };
 // operations counts loads and stores in one order, so a load issued between stores could only be
 // waited for together with the stores before it (a write round trip per channel).  Channels past K
 // read as 0 through the range check and are not stored.
-template <int KT>
+// ROWS2: the wave's two pixel tiles are the same 32 pixels of the rows py and py + 1 instead of 64 pixels of row py.
+template <int KT, bool ROWS2 = false>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[KT][2], float* __restrict__ yn, const Epi& ep, int kb, int kk,
                                             int K, int Ho, int Wo, int py, int px0) {
     float sc[KT][16], sh[KT][16];
@@ -71,14 +72,21 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[KT][2], float* _
             for (int t = 0; t < 2; ++t) {
                 float o = fmaf(acc[kt][t][e], sc[kt][e], sh[kt][e]);
                 if (ep.relu) o = fmaxf(o, 0.0f);
-                if (px0 + 32 * t < Wo) q[32 * t] = o;
+                if (ROWS2) {
+                    if (py + t < Ho && px0 < Wo) q[t * Wo] = o;
+                } else {
+                    if (px0 + 32 * t < Wo) q[32 * t] = o;
+                }
             }
         }
 }
 
 // KT: k-tiles of 32 output channels per wave (1 for a last block with at most 32 channels).
 // PAIR: the width is even and x is 8-byte aligned, so the columns 2px and 2px+1 come with one load.
-template <int KT, bool PAIR>
+// ROWS2: a wave owns 32 pixels of two consecutive output rows instead of 64 pixels of one (output widths
+// that fill the last 64-pixel segment less than half); filter rows outside the image then read zeros
+// instead of being skipped.
+template <int KT, bool PAIR, bool ROWS2>
 __global__ __launch_bounds__(256, 3) void conv3s2_kernel(const float* __restrict__ x, const float* __restrict__ Wg,
                                                       float* __restrict__ y, Epi ep, int C, int H, int W, int Ho, int Wo, int K,
                                                       int blocks_x, int blocks_y, int kblocks, int kb_base) {
@@ -88,10 +96,10 @@ __global__ __launch_bounds__(256, 3) void conv3s2_kernel(const float* __restrict
     const int bx = bid % blocks_x; bid /= blocks_x;
     const int by = bid % blocks_y;
     const int n = bid / blocks_y;
-    const int py = by * 4 + wave;                                // this wave's output row
+    const int py = ROWS2 ? 2 * (by * 4 + wave) : by * 4 + wave;  // this wave's (first) output row
     if (py >= Ho) return;
     const int kk = lane >> 5, nn = lane & 31;
-    const int px0 = bx * 64 + nn;                                // this lane's output pixels of the row: px0 and px0 + 32
+    const int px0 = bx * (ROWS2 ? 32 : 64) + nn;                 // this lane's output pixels: px0 and px0 + 32 of row py, or px0 of rows py and py + 1
     const int nchunks = C / CB;
     const int plane = H * W * 4;                                 // bytes of one input plane
 
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256, 3) void conv3s2_kernel(const float* __restrict
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int sx = 0; sx < 3; ++sx) {
-            const int col = 2 * (px0 + 32 * t) + sx - 1;
+            const int col = 2 * (px0 + (ROWS2 ? 0 : 32 * t)) + sx - 1;
             coff[sx][t] = (col >= 0 && col < W) ? kk * plane + col * 4 : OOB;
         }
     const int w_off = lane * 8;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 3) void conv3s2_kernel(const float* __restrict
             for (int e = 0; e < 16; ++e) acc[a][t][e] = 0.0f;
 
     const int iy = 2 * py - 1;                                   // input row of filter row 0
-    const int r_lo = iy < 0 ? 1 : 0, r_hi = iy + 2 >= H ? H - 1 - iy : 2;          // valid filter rows
+    const int r_lo = ROWS2 ? 0 : (iy < 0 ? 1 : 0), r_hi = ROWS2 ? 2 : (iy + 2 >= H ? H - 1 - iy : 2);      // filter rows to visit
     const int per_row = 2 * nchunks;                             // units of one filter row
     const int total = (r_hi - r_lo + 1) * per_row;
 
@@ -148,19 +156,26 @@ __global__ __launch_bounds__(256, 3) void conv3s2_kernel(const float* __restrict
             for (int kt = 0; kt < KT; ++kt)
                 a[lb][sx][kt] = __builtin_amdgcn_raw_buffer_load_b64(wrs, wv + (sx * 2 + kt) * 512, woff, 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int t = 0; t < 2; ++t) {
+            // ROWS2: the second tile is the next output row (two input rows further down); a filter row
+            // outside the image, or an output row past the last one, reads zeros
+            const int in_row = iy + lr + 2 * t;
+            const bool row_ok = !ROWS2 || (in_row >= 0 && in_row < H && py + t < Ho);
+            const int st = ROWS2 ? soff + t * 2 * W * 4 : soff;
+            const int c0 = row_ok ? coff[0][t] : OOB, c1 = row_ok ? coff[1][t] : OOB, c2 = row_ok ? coff[2][t] : OOB;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                b[lb][0][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[0][t], soff + 2 * j * plane, 0));
+            for (int j = 0; j < 2; ++j) {
+                b[lb][0][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, c0, st + 2 * j * plane, 0));
                 if (PAIR) {
-                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, coff[1][t], soff + 2 * j * plane, 0);
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, c1, st + 2 * j * plane, 0);
                     b[lb][1][j][t] = __uint_as_float(v[0]);
                     b[lb][2][j][t] = __uint_as_float(v[1]);
                 } else {
-                    b[lb][1][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[1][t], soff + 2 * j * plane, 0));
-                    b[lb][2][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, coff[2][t], soff + 2 * j * plane, 0));
+                    b[lb][1][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, c1, st + 2 * j * plane, 0));
+                    b[lb][2][j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, c2, st + 2 * j * plane, 0));
                 }
             }
+        }
         ++issued;
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256, 3) void conv3s2_kernel(const float* __restrict
         step(B2{}); load(B2{});
     }
 
-    store_tiles<KT>(acc, y + (int64_t)n * K * Ho * Wo, ep, kb, kk, K, Ho, Wo, py, px0);
+    store_tiles<KT, ROWS2>(acc, y + (int64_t)n * K * Ho * Wo, ep, kb, kk, K, Ho, Wo, py, px0);
 }
 
 // The 1x1 stride-2 convolution of the projection shortcuts: the same wave tile with a single tap (the
@@ -296,7 +311,9 @@ static int launch_s2(const char* name, const float* x, const float* arranged, fl
     if (C % CB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: C=%d is not a multiple of %d", name, C, CB);
     if ((int64_t)C * H * W * 4 >= (int64_t)OOB) return vo_fail(VO_ERR_UNSUPPORTED, "%s: one image of the input exceeds 1 GiB", name);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const int bx = (Wo + 63) / 64, by = (Ho + 3) / 4, kblocks = (K + KB - 1) / KB;
+    // two rows of 32 pixels per wave where 64-pixel segments would leave the last one at most half full
+    const bool rows2 = !ONE_TAP && (Wo + 31) / 32 * 32 < (Wo + 63) / 64 * 64;
+    const int bx = rows2 ? (Wo + 31) / 32 : (Wo + 63) / 64, by = rows2 ? (Ho + 7) / 8 : (Ho + 3) / 4, kblocks = (K + KB - 1) / KB;
     const int64_t blocks = (int64_t)bx * by * N;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
     const Epi ep{scale, shift, relu};
@@ -311,15 +328,21 @@ static int launch_s2(const char* name, const float* x, const float* arranged, fl
         if (full < kblocks) KERNEL(1)<<<ghalf, nt, 0, st>>>(x, arranged, y, ep, C, H, W, Ho, Wo, K, bx, by, 1, full); \
     } while (0)
 #define VO_S2_ONE(KT) conv1s2_kernel<KT>
-#define VO_S2_PAIR(KT) conv3s2_kernel<KT, true>
-#define VO_S2_SINGLE(KT) conv3s2_kernel<KT, false>
+#define VO_S2_PAIR(KT) conv3s2_kernel<KT, true, false>
+#define VO_S2_SINGLE(KT) conv3s2_kernel<KT, false, false>
+#define VO_S2_PAIR2(KT) conv3s2_kernel<KT, true, true>
+#define VO_S2_SINGLE2(KT) conv3s2_kernel<KT, false, true>
     if (ONE_TAP) VO_S2_LAUNCH(VO_S2_ONE);
+    else if (rows2 && pair) VO_S2_LAUNCH(VO_S2_PAIR2);
+    else if (rows2) VO_S2_LAUNCH(VO_S2_SINGLE2);
     else if (pair) VO_S2_LAUNCH(VO_S2_PAIR);
     else VO_S2_LAUNCH(VO_S2_SINGLE);
 #undef VO_S2_LAUNCH
 #undef VO_S2_ONE
 #undef VO_S2_PAIR
 #undef VO_S2_SINGLE
+#undef VO_S2_PAIR2
+#undef VO_S2_SINGLE2
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;

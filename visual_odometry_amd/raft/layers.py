@@ -194,14 +194,14 @@ def _conv7x7_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
 def _conv3x3s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached arranged weights when this convolution can run on the streaming 3x3 stride-2
     matrix-core kernel (float32, input channels a multiple of 8, an output width that fills the
-    kernel's 64-pixel row segments to at least 60 %), else None."""
+    kernel's 32- or 64-pixel row segments to at least 60 %), else None."""
     if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] % 8 == 0
             and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
         return None
     wo = (x.shape[3] - 1) // 2 + 1
-    if wo < 0.6 * ((wo + 63) // 64 * 64):
+    if wo < 0.6 * ((wo + 31) // 32 * 32):
         return None
     key = (weight._version, weight.data_ptr())
     cached = getattr(weight, "_vo_conv3x3s2", None)
