@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="frame pairs per step and per GPU")
+    ap.add_argument("--batch", type=int, default=192, help="frame pairs per step and per GPU")
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
