@@ -47,6 +47,28 @@ def test_chunking_and_oracle_poses(vo):
             np.testing.assert_allclose(T[i].cpu().numpy(), Tr, atol=1e-6)
 
 
+def test_full_size_chunk_invariance(vo):
+    """The benchmark configuration itself (640x480, 12 iterations, 300 keypoints): 20 frame pairs as
+    one chunk and as ragged chunks of 7, 7 and 6 with the cached halo depth give the same skip flags
+    and the same poses (every convolution runs on the hand-written kernels, whose per-image result
+    does not depend on the batch; the tolerance covers the order of the float64 statistics atomics)."""
+    H, W, F = 480, 640, 21
+    pipe = _vo(H, W, iters=12, n_kp=300)
+    left, right = syn.stereo_sequence(21, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    T_all, sk_all = pipe.run(l, r, chunk_pairs=F - 1)
+    T_chunks, sk_chunks = pipe.run(l, r, chunk_pairs=7)
+    assert T_all.shape == (F - 1, 4, 4) and torch.equal(sk_all, sk_chunks)
+    ok = ~sk_all
+    assert int(ok.sum()) > 0
+    assert (T_all[ok] - T_chunks[ok]).abs().max().item() < 1e-6
+    # every pose is a rigid transform
+    R = T_all[ok][:, :3, :3]
+    eye = torch.eye(3, dtype=R.dtype, device=R.device)
+    assert (R @ R.transpose(1, 2) - eye).abs().max().item() < 1e-9
+    assert (torch.linalg.det(R) - 1).abs().max().item() < 1e-9
+
+
 def test_recovers_known_motion_from_exact_maps(vo):
     """Planar scenes with exact depth/flow: the pose kernel chain recovers the
     synthetic camera motion (accuracy is limited by the truncated-pixel depth
