@@ -362,8 +362,10 @@ int vo_kabsch_batch(const double* P, const double* Q, const uint8_t* weight,
  * A hypothesis' inliers are the weighted points with |R p + t - q| < threshold; the
  * FIRST hypothesis with the strictly largest count wins and the pose is refitted on
  * its inliers (identity when fewer than 3).  The reference samples from NumPy's
- * unseeded global generator; here triple h of pair b is a pure function of
- * (seed, b, h): s = splitmix64(seed ^ (b << 32 | h)); i0 = s % n;
+ * unseeded global generator; here triple h of the batch's item i is a pure function of
+ * (seed, b, h) with b = first_pair + i, the pair's index in the whole sequence (so that the
+ * result does not depend on how a sequence is cut into batches or shards; b is taken
+ * modulo 2^32): s = splitmix64(seed ^ (b << 32 | h)); i0 = s % n;
  * s = splitmix64(s); i1 = s % (n-1), skipping i0; s = splitmix64(s); i2 = s % (n-2),
  * skipping both (n = number of weighted points, indices into their compacted order).
  * T_out: (B,4,4) float64; n_inliers_out: (B) int32 inliers of the winner (-1 when a
@@ -372,7 +374,7 @@ int vo_kabsch_batch(const double* P, const double* Q, const uint8_t* weight,
 int vo_ransac_kabsch_batch(const double* P, const double* Q, const uint8_t* weight,
                            double threshold, int iterations, uint64_t seed,
                            double* T_out, int32_t* n_inliers_out, uint8_t* inlier_mask_out,
-                           int batch, int N, void* stream);
+                           int batch, int N, int64_t first_pair, void* stream);
 
 #ifdef __cplusplus
 }

@@ -218,11 +218,12 @@ def _splitmix64(x: int) -> int:
 def counter_triples(seed: int, pair: int):
     """The hypothesis triples of the HIP RANSAC kernel (include/vo_hip.h,
     vo_ransac_kabsch_batch) as a ``choice`` callable for ``ransac_kabsch``: call h
-    returns triple h of ``pair``, three distinct indices in [0, n)."""
+    returns triple h of ``pair`` -- the pair's index in the whole SEQUENCE (taken modulo
+    2^32), not its position in a chunk -- three distinct indices in [0, n)."""
     state = {"h": 0}
 
     def choice(n: int):
-        s = _splitmix64((seed & _M64) ^ ((pair << 32) | state["h"]))
+        s = _splitmix64((seed & _M64) ^ (((pair & 0xFFFFFFFF) << 32) | state["h"]))
         state["h"] += 1
         i0 = s % n
         s = _splitmix64(s)

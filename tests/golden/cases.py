@@ -113,6 +113,39 @@ def kabsch_batch(seed=9, batch=4096, n=64):
     return P, Q
 
 
+def ransac_cases(seed=61):
+    """name -> (P, Q, threshold, iterations, numpy_seed) for CameraRansacXform.  The reference
+    draws its triples from NumPy's global stream (camera/camera_svd_xform.py:98), which
+    ``np.random.seed(numpy_seed)`` right before the call makes reproducible.
+      outliers     120 points, a quarter of them gross outliers
+      small_noisy  12 points with noise of the order of the threshold: inlier counts are small
+                   integers, many hypotheses tie, so the first-wins rule decides the refit set
+      n3           the minimal input (every draw is a permutation of the same triple)
+      fallback     unrelated point sets and a tight threshold: no hypothesis reaches 3 inliers
+                   and the identity comes back
+      two_inliers  a hypothesis can reach 2 inliers but never 3: still the identity"""
+    rng = np.random.default_rng(seed)
+    out = {}
+
+    def cloud(n):
+        P = rng.uniform(-3, 3, (n, 3)); P[:, 2] = rng.uniform(0.5, 15, n)
+        return P
+
+    P = cloud(120); R = syn.random_rotation(rng, 0.1); t = rng.uniform(-0.15, 0.15, 3)
+    Q = P @ R.T + t + rng.normal(0, 2e-3, P.shape)
+    Q[:30] += rng.uniform(-1, 1, (30, 3))
+    out["outliers"] = (P, Q, 0.05, 200, 1234)
+    P = cloud(12); R = syn.random_rotation(rng, 0.05); t = rng.uniform(-0.15, 0.15, 3)
+    out["small_noisy"] = (P, P @ R.T + t + rng.normal(0, 0.04, P.shape), 0.05, 200, 99)
+    P = cloud(3); R = syn.random_rotation(rng, 0.05); t = rng.uniform(-0.15, 0.15, 3)
+    out["n3"] = (P, P @ R.T + t + rng.normal(0, 1e-3, P.shape), 0.05, 50, 5)
+    out["fallback"] = (cloud(40), cloud(40), 1e-3, 100, 7)
+    P = cloud(4); Q = cloud(4)
+    Q[:2] = P[:2] + np.array([0.1, -0.2, 0.05])         # two points move rigidly, the other two do not
+    out["two_inliers"] = (P, Q, 1e-6, 100, 11)
+    return out
+
+
 def trace_case(seed=21, pairs=8, h=480, w=640, noise_px=0.1):
     """Eight planar-scene frame pairs for the end-to-end geometry trace."""
     rng = np.random.default_rng(seed)

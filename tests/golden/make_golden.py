@@ -24,11 +24,11 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+REF = next((a for a in sys.argv[1:] if not a.startswith("--")), "/root/reference")
 sys.path.insert(0, REF)
 sys.modules.setdefault("cv2", types.ModuleType("cv2"))
 
-from camera.camera_svd_xform import CameraSvdXform            # noqa: E402
+from camera.camera_svd_xform import CameraRansacXform, CameraSvdXform   # noqa: E402
 from keypoints.keypoints_3d import Keypoints3DXform            # noqa: E402
 from keypoints.keypoints_3d_flow import Keypoints3DFlow        # noqa: E402
 from keypoints.keypoints_uniform import UniformKeyPoints       # noqa: E402
@@ -40,7 +40,12 @@ from tests.golden import cases                                 # noqa: E402
 from visual_odometry_amd import synthetic as syn               # noqa: E402
 
 
+ONLY = [a[len("--only="):] for a in sys.argv[1:] if a.startswith("--only=")]    # e.g. --only=g6_ransac
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
@@ -102,6 +107,16 @@ def main():
     out["batch_T"] = T
     out["in_sum"] = cases.checksum(P, Q)
     save("g5_kabsch", **out)
+
+    # G6 RANSAC pose: the global NumPy stream seeded right before each call ------------
+    out = {}
+    for name, (P, Q, thr, iters, np_seed) in cases.ransac_cases().items():
+        np.random.seed(np_seed)
+        R, t = CameraRansacXform(thr, iters).compute_camera_xform(P, Q)
+        out[name + "_R"] = R
+        out[name + "_t"] = t
+    out["in_sum"] = cases.checksum(*[a for c in cases.ransac_cases().values() for a in c[:2]])
+    save("g6_ransac", **out)
 
     # G7 eight-pair trace of test_camera_tracking.py:176-210 ---------------------
     h, w = 480, 640

@@ -102,3 +102,52 @@ def test_uniform_keypoints_host_matches_golden():
         for mname, mask in cases.grid_masks(h, w, seed=h + n + margin).items():
             got = UniformKeyPoints(mask, margin).get_keypoints(None, n)
             assert np.array_equal(got, g[f"{h}x{w}_n{n}_m{margin}_{mname}"])
+
+
+_REFERENCE = "/root/reference"
+
+_DROP_IN_CHECK = r"""
+import contextlib, io, sys, types
+sys.dont_write_bytecode = True
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+with_cv2_stub = sys.argv[3] == "stub"
+if with_cv2_stub:
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+from visual_odometry_amd import geometry, interfaces, raft_plugins, rectification, synthetic as syn
+from flow.flow_interfaces import OpticalFlowInterface
+from stereo.stereo_interfaces import StereoDisparityInterface, StereoParamsInterface, StereoRectificationInterface
+from camera.camera_interfaces import CameraXformInterface
+from stereo.stereo_params_YAML import StereoParamsYAML
+assert interfaces.REFERENCE_ABCS["flow"] and interfaces.REFERENCE_ABCS["stereo"] and interfaces.REFERENCE_ABCS["camera"]
+assert interfaces.REFERENCE_ABCS["keypoints"] == with_cv2_stub
+assert issubclass(raft_plugins.HipOpticalFlowRAFT, OpticalFlowInterface)
+assert issubclass(raft_plugins.HipDisparityRAFT, StereoDisparityInterface)
+assert issubclass(rectification.HipStereoRectification, StereoRectificationInterface)
+assert issubclass(geometry.HipCameraSvdXform, CameraXformInterface)
+assert issubclass(geometry.HipCameraRansacXform, CameraXformInterface)
+if with_cv2_stub:
+    from keypoints.keypoints_interfaces import KeyPointsInterface, Keypoints3DFlowInterface, Keypoints3DInterface
+    assert issubclass(geometry.UniformKeyPoints, KeyPointsInterface)
+    assert issubclass(geometry.HipKeypoints3DXform, Keypoints3DInterface)
+    assert issubclass(geometry.HipKeypoints3DFlow, Keypoints3DFlowInterface)
+with contextlib.redirect_stdout(io.StringIO()):
+    params = StereoParamsYAML(syn.RIG_YAML)           # a genuine reference parameter object
+assert isinstance(params, StereoParamsInterface)
+depth = geometry.HipStereoDepth(params)               # the constructor needs no GPU
+assert depth.fx == params.focal_length_px and depth.baseline == params.get_baseline()
+print("ok")
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(_REFERENCE, "flow")), reason="reference checkout not present")
+@pytest.mark.parametrize("cv2", ["stub", "absent"])
+def test_backends_subclass_the_reference_interfaces(cv2):
+    """With the reference's root on sys.path every Hip* class derives from the reference's OWN
+    abstract class; where cv2 is missing only the keypoint interfaces (whose module imports cv2)
+    fall back to the local stand-ins, and HipStereoDepth still accepts a reference
+    StereoParamsYAML.  Runs in a child process: the choice is made at import time."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _DROP_IN_CHECK, _REFERENCE, ROOT, cv2], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

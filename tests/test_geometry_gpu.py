@@ -213,6 +213,20 @@ def test_ransac_matches_oracle_with_same_triples(vo):
             np.testing.assert_allclose(T[b, :3, 3], tr, atol=1e-9)
             assert rot_angle(T[b, :3, :3], truth[b][0]) < 5e-3          # outliers rejected
             assert mask[b].sum() == n_inl[b] and not mask[b][~sel].any()
+    # the triples are keyed on the pair's index in the SEQUENCE: items 2.. of the batch handed
+    # over as a batch of their own with first_pair=2 (and 2 + 2^32, the index is taken modulo
+    # 2^32) reproduce the same poses bit for bit, and match the oracle fed the global index
+    T_all, n_all = ops.ransac_kabsch_batch(Pd, Qd, wd, 0.05, 200, seed=1234)
+    for base in (2, 2 + 2 ** 32):
+        T_tail, n_tail = ops.ransac_kabsch_batch(Pd[2:].contiguous(), Qd[2:].contiguous(), wd[2:].contiguous(),
+                                                 0.05, 200, seed=1234, first_pair=base)
+        assert torch.equal(T_tail, T_all[2:]) and torch.equal(n_tail, n_all[2:])
+    T_off, _ = ops.ransac_kabsch_batch(Pd[:1], Qd[:1], None, 0.05, 200, seed=1234, first_pair=41)
+    Rr, tr = ref.ransac_kabsch(P[0], Q[0], 0.05, 200, choice=ref.counter_triples(1234, 41))
+    np.testing.assert_allclose(T_off[0, :3, :3].cpu().numpy(), Rr, atol=1e-9)
+    np.testing.assert_allclose(T_off[0, :3, 3].cpu().numpy(), tr, atol=1e-9)
+    with pytest.raises(ValueError):
+        ops.ransac_kabsch_batch(Pd, Qd, None, 0.05, 10, first_pair=-1)
             err = np.linalg.norm(P[b] @ T[b, :3, :3].T + T[b, :3, 3] - Q[b], axis=1)
             assert n_inl[b] > 0.6 * sel.sum() and np.median(err[mask[b]]) < 0.02
     # the drop-in class: same signature, same exceptions as the reference

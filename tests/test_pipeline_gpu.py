@@ -11,10 +11,11 @@ from visual_odometry_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def _vo(H, W, iters=2, n_kp=120):
+def _vo(H, W, iters=2, n_kp=120, pose="svd", stereo=None):
     from visual_odometry_amd.pipeline import VisualOdometry, VOConfig
     from visual_odometry_amd.raft.models import RAFTStereoConfig
-    cfg = VOConfig(iters=iters, stereo=RAFTStereoConfig.realtime(), max_keypoints=n_kp, camera_offset=syn.CAMERA_OFFSET)
+    cfg = VOConfig(iters=iters, stereo=stereo or RAFTStereoConfig.realtime(), max_keypoints=n_kp,
+                   camera_offset=syn.CAMERA_OFFSET, pose=pose, ransac_iterations=200)
     return VisualOdometry(cfg, syn.left_K(W / 640.0), syn.focal_length_px() * (W / 640.0), syn.baseline(),
                           np.ones((H, W), bool), seed=0)
 
@@ -67,6 +68,83 @@ def test_full_size_chunk_invariance(vo):
     eye = torch.eye(3, dtype=R.dtype, device=R.device)
     assert (R @ R.transpose(1, 2) - eye).abs().max().item() < 1e-9
     assert (torch.linalg.det(R) - 1).abs().max().item() < 1e-9
+
+
+@pytest.mark.parametrize("pose", ["svd", "ransac"])
+def test_virtual_shards_equal_the_unsharded_run(vo, pose):
+    """Two ranks' shards run one after the other on this GPU -- each from its own halo frame,
+    whose depth it recomputes (test_camera_tracking.py:136-150), ragged chunks inside -- give the
+    skip flags and poses of the unsharded run, and so does a different chunk size.  With the
+    RANSAC estimator this holds because the hypothesis triples follow the pair's index in the
+    sequence, not its position in a chunk or shard."""
+    from visual_odometry_amd.pipeline import compose_trajectory
+    H, W, F = 96, 128, 10
+    pipe = _vo(H, W, pose=pose)
+    left, right = syn.stereo_sequence(17, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    T_all, sk_all = pipe.run(l, r, chunk_pairs=F - 1)
+    T_c, sk_c = pipe.run(l, r, chunk_pairs=4)
+    assert torch.equal(sk_all, sk_c)
+    parts = [pipe.run_shard(l, r, rank, 2, chunk_pairs=2) for rank in range(2)]
+    assert [(p[0], p[1]) for p in parts] == [(0, 5), (5, 9)]
+    T_s, sk_s = torch.cat([p[2] for p in parts]), torch.cat([p[3] for p in parts])
+    assert torch.equal(sk_all, sk_s) and int((~sk_all).sum()) > 0
+    ok = ~sk_all
+    # same frames, same kernels, per-image results independent of the batch: 1e-6 covers the
+    # order of the float64 statistics atomics in the instance-norm layers
+    assert (T_all[ok] - T_c[ok]).abs().max().item() < 1e-6
+    assert (T_all[ok] - T_s[ok]).abs().max().item() < 1e-6
+    Ga = compose_trajectory(T_all.cpu().numpy(), sk_all.cpu().numpy())
+    Gs = compose_trajectory(T_s.cpu().numpy(), sk_s.cpu().numpy())
+    np.testing.assert_allclose(Gs, Ga, atol=1e-5)
+    # three ranks over 9 pairs, and more ranks than pairs: empty blocks are legal
+    parts3 = [pipe.run_shard(l[:3], r[:3], rank, 4, chunk_pairs=8) for rank in range(4)]
+    assert [p[2].shape[0] for p in parts3] == [1, 1, 0, 0]
+    ok2 = ~sk_all[:2]
+    assert torch.equal(torch.cat([p[3] for p in parts3]), sk_all[:2])
+    if bool(ok2.any()):
+        assert (torch.cat([p[2] for p in parts3])[ok2] - T_all[:2][ok2]).abs().max().item() < 1e-6
+
+
+def test_host_frames_are_uploaded_chunk_by_chunk(vo):
+    """Pinned host frames go up on a second stream, one chunk ahead of the computation; the
+    poses equal those from frames already resident in HBM bit for bit."""
+    H, W, F = 96, 128, 9
+    pipe = _vo(H, W)
+    left, right = syn.stereo_sequence(19, F, H, W)
+    lh, rh = torch.from_numpy(left).pin_memory(), torch.from_numpy(right).pin_memory()
+    T_dev, sk_dev = pipe.run(lh.cuda(), rh.cuda(), chunk_pairs=3)
+    T_host, sk_host = pipe.run(lh, rh, chunk_pairs=3)
+    assert T_host.is_cuda and torch.equal(sk_dev, sk_host)
+    assert (T_host[~sk_host] - T_dev[~sk_dev]).abs().max().item() < 1e-6
+
+
+def test_run_sharded_through_a_single_rank_rccl_group(vo):
+    """The product entry point over a real nccl (RCCL) process group of one rank: shard ->
+    run -> all_gather on device memory -> host composition equals run() + compose."""
+    import os
+    import torch.distributed as dist
+    from visual_odometry_amd.pipeline import compose_trajectory
+    H, W, F = 96, 128, 6
+    pipe = _vo(H, W)
+    left, right = syn.stereo_sequence(23, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    T, sk = pipe.run(l, r, chunk_pairs=3)
+    want = compose_trajectory(T.cpu().numpy(), sk.cpu().numpy())
+    # without a process group: the single-GPU loop
+    T0, s0, G0 = pipe.run_sharded(l, r, chunk_pairs=3)
+    np.testing.assert_allclose(G0, want, atol=1e-6)
+    assert not dist.is_initialized()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        T1, s1, G1 = pipe.run_sharded(l, r, chunk_pairs=3)
+    finally:
+        dist.destroy_process_group()
+    assert T1.shape == (F - 1, 4, 4) and np.array_equal(s1, sk.cpu().numpy())
+    np.testing.assert_allclose(T1[~s1], T.cpu().numpy()[~s1], atol=1e-6)
+    np.testing.assert_allclose(G1, want, atol=1e-6)
 
 
 def test_recovers_known_motion_from_exact_maps(vo):

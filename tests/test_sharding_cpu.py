@@ -9,7 +9,8 @@ import torch.multiprocessing as mp
 
 from oracle import geometry_ref as ref
 from visual_odometry_amd import synthetic as syn
-from visual_odometry_amd.pipeline import compose_trajectory, gather_poses, shard_pairs, shard_segments, write_trajectory
+from visual_odometry_amd.pipeline import (compose_trajectory, gather_poses, run_shard, run_sharded, shard_pairs,
+                                          shard_segments, write_trajectory)
 
 
 def _poses(n, seed=0):
@@ -93,6 +94,76 @@ def test_gather_poses_two_ranks_gloo(n_pairs):
             np.testing.assert_array_equal(z["T"], T)          # float64 payload survives bit for bit
             np.testing.assert_array_equal(z["s"], skipped)
             np.testing.assert_array_equal(compose_trajectory(z["T"], z["s"]), ref.compose_trajectory(T, skipped))
+
+
+def _fake_frames(n_frames, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randint(0, 255, (n_frames, 4, 6), dtype=torch.uint8, generator=g),
+            torch.randint(0, 255, (n_frames, 4, 6), dtype=torch.uint8, generator=g))
+
+
+def _fake_run(left, right, chunk_pairs=8, first_pair=0):
+    """Stands in for VisualOdometry.run on a box without a GPU: pair i's "pose" is a function of
+    the CONTENT of frames i and i+1 and of its global index, and it is skipped when frame i+1's
+    first pixel is even -- so a shard that is handed the wrong frames, the wrong halo or the wrong
+    pair offset cannot reproduce the unsharded result."""
+    n = max(left.shape[0] - 1, 0)
+    T = torch.zeros((n, 4, 4), dtype=torch.float64)
+    sk = torch.zeros((n,), dtype=torch.bool)
+    for i in range(n):
+        a = left[i].double().mean().item() / 255.0
+        b = (right[i + 1].double().mean().item() / 255.0) + 1e-3 * (first_pair + i)
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        T[i] = torch.eye(4, dtype=torch.float64)
+        T[i, :3, :3] = torch.from_numpy(R)
+        T[i, :3, 3] = torch.tensor([b, -b, a * b], dtype=torch.float64)
+        sk[i] = bool(int(left[i + 1, 0, 0]) % 2 == 0)
+    return T, sk
+
+
+def _sharded_worker(rank, world, n_frames, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    left, right = _fake_frames(n_frames)
+    T, sk, G = run_sharded(_fake_run, left, right, chunk_pairs=3)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), T=T, s=sk, G=G)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [12, 6, 2])
+def test_run_sharded_two_ranks_gloo(n_frames):
+    """shard -> halo frame -> run -> all_gather -> composition over two processes equals the
+    unsharded loop (n_frames=2: one pair, the second rank's block is empty)."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000) + n_frames
+    left, right = _fake_frames(n_frames)
+    T, sk = _fake_run(left, right)
+    want = compose_trajectory(T.numpy(), sk.numpy())
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_sharded_worker, args=(world, n_frames, port, d), nprocs=world, join=True)
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            np.testing.assert_array_equal(z["T"][~z["s"]], T.numpy()[~sk.numpy()])
+            np.testing.assert_array_equal(z["s"], sk.numpy())
+            np.testing.assert_array_equal(z["G"], want)
+
+
+def test_run_shard_hands_over_the_halo_frame():
+    left, right = _fake_frames(11)
+    seen = []
+
+    def spy(l, r, chunk_pairs=8, first_pair=0):
+        seen.append((l.shape[0], first_pair, l[:1].clone()))
+        return _fake_run(l, r, chunk_pairs, first_pair)
+    blocks = [run_shard(spy, left, right, rank, 3, 4) for rank in range(3)]
+    assert [(b[0], b[1]) for b in blocks] == [(0, 4), (4, 8), (8, 10)]
+    assert [(n, fp) for n, fp, _ in seen] == [(5, 0), (5, 4), (3, 8)]        # pairs + one halo frame
+    for (s, _, _, _), (_, _, first) in zip(blocks, seen):
+        assert torch.equal(first[0], left[s])
+    T, sk = _fake_run(left, right)
+    assert torch.equal(torch.cat([b[2] for b in blocks]), T) and torch.equal(torch.cat([b[3] for b in blocks]), sk)
 
 
 def test_gather_without_process_group_is_identity():

@@ -60,7 +60,7 @@ SIGNATURES = {
     "vo_keypoints_to_2d": [_P, _P, _P, _P, _L, _P],
     "vo_track_keypoints": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "vo_kabsch_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "vo_ransac_kabsch_batch": [_P, _P, _P, _D, _I, c_uint64, _P, _P, _P, _I, _I, _P],
+    "vo_ransac_kabsch_batch": [_P, _P, _P, _D, _I, c_uint64, _P, _P, _P, _I, _I, _L, _P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["vo_version", "vo_last_error"])
 

@@ -175,12 +175,12 @@ int launch_corr(const float* A, const float* B, float* C, int groups, int M, int
     if (nwg > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: %lld workgroups", name, (long long)nwg);
     constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + PAD) * sizeof(float);
     auto kern = corr_abt_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
+    if (lds > 48 * 1024) {
+        // the attribute is kept per device and setting it is a cheap host call: set it on every
+        // launch rather than remember it in a flag that another device or thread would not share
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: LDS attribute: %s", name, hipGetErrorString(e));
-        attr_done = true;
     }
     kern<<<dim3((unsigned)nwg), dim3(64 * WAVES_M * WAVES_N), lds, stream>>>(A, B, C, M, N, K, sA, sB, sC, tiles_m,
                                                                              tiles_n, (unsigned)nwg, divisor);

@@ -12,7 +12,8 @@
 //
 // The reference draws from NumPy's unseeded global stream, so its result is not
 // reproducible run to run; here the triples are a pure function of
-// (seed, pair index, hypothesis index), restated in oracle/geometry_ref.py.
+// (seed, pair index in the whole sequence, hypothesis index), so a trajectory does
+// not depend on how the sequence is cut into chunks or shards.
 #include "vo_common.h"
 #include "vo_svd3.h"
 
@@ -85,7 +86,7 @@ __device__ __forceinline__ double wave_sum(double x) {
 
 __global__ __launch_bounds__(THREADS) void ransac_kernel(const double* __restrict__ P, const double* __restrict__ Q,
                                                         const uint8_t* __restrict__ wgt, double thr, int iterations,
-                                                        uint64_t seed, double* __restrict__ T,
+                                                        uint64_t seed, uint32_t first_pair, double* __restrict__ T,
                                                         int32_t* __restrict__ n_inl_out,
                                                         uint8_t* __restrict__ mask_out, int N) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(THREADS) void ransac_kernel(const double* __restric
     uint16_t* list = reinterpret_cast<uint16_t*>(shared_n + 4);               // [N]
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t pair = first_pair + (uint32_t)b;      // the pair's index in the whole sequence keys its triples
     const double* p = P + (int64_t)b * N * 3;
     const double* q = Q + (int64_t)b * N * 3;
     const uint8_t* w = wgt ? wgt + (int64_t)b * N : nullptr;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(THREADS) void ransac_kernel(const double* __restric
             Rigid x;
             if (live) {
                 uint32_t r[3], g[3];
-                draw_triple(seed, (uint32_t)b, (uint32_t)hyp, (uint32_t)n, r);
+                draw_triple(seed, pair, (uint32_t)hyp, (uint32_t)n, r);
                 g[0] = list[r[0]]; g[1] = list[r[1]]; g[2] = list[r[2]];
                 fit3(p, q, g, x);
             }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(THREADS) void ransac_kernel(const double* __restric
     if (win_cnt >= 3 && best_hyp == win_hyp && best_cnt == win_cnt) {          // exactly one lane owns it
         uint32_t r[3], g[3];
         Rigid x;
-        draw_triple(seed, (uint32_t)b, (uint32_t)win_hyp, (uint32_t)n, r);
+        draw_triple(seed, pair, (uint32_t)win_hyp, (uint32_t)n, r);
         g[0] = list[r[0]]; g[1] = list[r[1]]; g[2] = list[r[2]];
         fit3(p, q, g, x);
 #pragma unroll
@@ -240,22 +242,22 @@ __global__ __launch_bounds__(THREADS) void ransac_kernel(const double* __restric
 
 extern "C" int vo_ransac_kabsch_batch(const double* P, const double* Q, const uint8_t* weight, double threshold,
                                       int iterations, uint64_t seed, double* T_out, int32_t* n_inliers_out,
-                                      uint8_t* inlier_mask_out, int batch, int N, void* stream) {
+                                      uint8_t* inlier_mask_out, int batch, int N, int64_t first_pair, void* stream) {
     VO_REQUIRE(P && Q && T_out && n_inliers_out, "vo_ransac_kabsch_batch: null pointer");
     VO_REQUIRE(batch > 0 && iterations > 0, "vo_ransac_kabsch_batch: bad sizes batch=%d iterations=%d", batch, iterations);
+    VO_REQUIRE(first_pair >= 0, "vo_ransac_kabsch_batch: first_pair=%lld is negative", (long long)first_pair);
     VO_REQUIRE(N >= 3, "vo_ransac_kabsch_batch: at least 3 points are required for RANSAC (N=%d)", N);
     if (N > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_ransac_kabsch_batch: N=%d exceeds the 65535-point index list", N);
     const size_t lds = (size_t)(TILE * 6 + 12) * sizeof(double) + (2 * THREADS + 4) * sizeof(int) +
                        (((size_t)N * sizeof(uint16_t) + 15) & ~(size_t)15);
-    static bool attr_done = false;
-    if (!attr_done) {
+    {   // per-device attribute, cheap to set: no process-wide flag
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "vo_ransac_kabsch_batch: LDS attribute: %s", hipGetErrorString(e));
-        attr_done = true;
     }
     ransac_kernel<<<dim3((unsigned)batch), dim3(THREADS), lds, vo_stream(stream)>>>(
-        P, Q, weight, threshold, iterations, seed, T_out, n_inliers_out, inlier_mask_out, N);
+        P, Q, weight, threshold, iterations, seed, (uint32_t)((uint64_t)first_pair & 0xffffffffu), T_out, n_inliers_out,
+        inlier_mask_out, N);
     VO_CHECK_LAUNCH("vo_ransac_kabsch_batch");
     return VO_OK;
 }

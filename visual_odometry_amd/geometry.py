@@ -226,9 +226,11 @@ class HipCameraSvdXform(CameraXformInterface):
         T = T[0].cpu().numpy()
         return T[:3, :3].copy(), T[:3, 3].copy()
 
-    def compute_camera_xform_batch(self, P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None):
+    def compute_camera_xform_batch(self, P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None,
+                                   first_pair: int = 0):
         """(B,N,3) float64 GPU point sets (+ optional (B,N) uint8 weights) ->
-        T (B,4,4) float64, n_used (B) int32."""
+        T (B,4,4) float64, n_used (B) int32.  ``first_pair`` is accepted for symmetry with the
+        RANSAC estimator and ignored (the fit is deterministic)."""
         return ops.kabsch_batch(P, Q, weight, self.offset)
 
 
@@ -251,7 +253,10 @@ class HipCameraRansacXform(CameraXformInterface):
         T = T[0].cpu().numpy()
         return T[:3, :3].copy(), T[:3, 3].copy()
 
-    def compute_camera_xform_batch(self, P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None):
+    def compute_camera_xform_batch(self, P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None,
+                                   first_pair: int = 0):
         """(B,N,3) float64 GPU point sets (+ optional (B,N) uint8 weights) ->
-        T (B,4,4) float64, n_inliers (B) int32 (-1: fewer than 3 weighted points)."""
-        return ops.ransac_kabsch_batch(P, Q, weight, self.threshold, self.iterations, self.seed)
+        T (B,4,4) float64, n_inliers (B) int32 (-1: fewer than 3 weighted points).
+        ``first_pair``: sequence index of item 0 (keys the hypothesis triples)."""
+        return ops.ransac_kabsch_batch(P, Q, weight, self.threshold, self.iterations, self.seed,
+                                       first_pair=first_pair)

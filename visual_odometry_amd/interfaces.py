@@ -16,41 +16,41 @@ from abc import ABC, abstractmethod
 from enum import Enum
 
 
-def _try_reference():
+def _try_import(module: str, names):
+    """The named classes of one reference module, or None when the reference tree is not on
+    ``sys.path`` or that module cannot be imported (keypoints/keypoints_interfaces.py:2 imports
+    cv2, which may be absent).  Each module is tried on its own: one failing import must not
+    turn the other interfaces into local stand-ins, or a genuine reference object (say a
+    ``StereoParamsYAML``) would fail the ``isinstance`` checks of the classes built on them."""
     try:
-        from flow.flow_interfaces import OpticalFlowInterface as F                      # type: ignore
-        from stereo.stereo_interfaces import (CameraParametersInterface as C,           # type: ignore
-                                              StereoDisparityInterface as D,
-                                              StereoParamsInterface as P,
-                                              StereoRectificationInterface as R)
-        from keypoints.keypoints_interfaces import (KeyPointsInterface as K,            # type: ignore
-                                                    Keypoints3DInterface as K3,
-                                                    Keypoints3DFlowInterface as K3F)
-        from camera.camera_interfaces import CameraXformInterface as X                   # type: ignore
-        return dict(F=F, C=C, D=D, P=P, R=R, K=K, K3=K3, K3F=K3F, X=X)
-    except Exception:       # reference tree absent, or one of its imports (cv2) is
+        mod = __import__(module, fromlist=list(names))
+        return [getattr(mod, n) for n in names]
+    except Exception:
         return None
 
 
-_ref = _try_reference()
-USING_REFERENCE_ABCS = _ref is not None
+_flow = _try_import("flow.flow_interfaces", ["OpticalFlowInterface"])
+_stereo = _try_import("stereo.stereo_interfaces", ["CameraParametersInterface", "StereoParamsInterface",
+                                                   "StereoRectificationInterface", "StereoDisparityInterface"])
+_keypoints = _try_import("keypoints.keypoints_interfaces", ["KeyPointsInterface", "Keypoints3DInterface",
+                                                            "Keypoints3DFlowInterface"])
+_camera = _try_import("camera.camera_interfaces", ["CameraXformInterface"])
+# which interface families come from the reference's own modules
+REFERENCE_ABCS = {"flow": _flow is not None, "stereo": _stereo is not None, "keypoints": _keypoints is not None,
+                  "camera": _camera is not None}
+USING_REFERENCE_ABCS = all(REFERENCE_ABCS.values())
 
-if _ref is not None:
-    OpticalFlowInterface = _ref["F"]
-    CameraParametersInterface = _ref["C"]
-    StereoDisparityInterface = _ref["D"]
-    StereoParamsInterface = _ref["P"]
-    StereoRectificationInterface = _ref["R"]
-    KeyPointsInterface = _ref["K"]
-    Keypoints3DInterface = _ref["K3"]
-    Keypoints3DFlowInterface = _ref["K3F"]
-    CameraXformInterface = _ref["X"]
+if _flow is not None:
+    (OpticalFlowInterface,) = _flow
 else:
     class OpticalFlowInterface(ABC):
         @abstractmethod
         def compute_flow(self, img1, img2):
             """Two images -> flow (2,H,W) float32, channel 0 = du, channel 1 = dv."""
 
+if _stereo is not None:
+    CameraParametersInterface, StereoParamsInterface, StereoRectificationInterface, StereoDisparityInterface = _stereo
+else:
     class CameraParametersInterface(ABC):
         @abstractmethod
         def get_intrinsics(self): ...
@@ -93,6 +93,9 @@ else:
         def compute_disparity(self, img_left, img_right):
             """Rectified pair -> disparity (H,W) float32 (negative: left->right x-flow)."""
 
+if _keypoints is not None:
+    KeyPointsInterface, Keypoints3DInterface, Keypoints3DFlowInterface = _keypoints
+else:
     class KeyPointsInterface(ABC):
         @abstractmethod
         def get_keypoints(self, image, max_number: int): ...
@@ -111,6 +114,9 @@ else:
         @abstractmethod
         def compute_3d_flow(self, keypoints, depth1, depth2, uv_flow): ...
 
+if _camera is not None:
+    (CameraXformInterface,) = _camera
+else:
     class CameraXformInterface(ABC):
         @abstractmethod
         def compute_camera_xform(self, P, Q): ...

@@ -772,8 +772,11 @@ def kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None =
 
 
 def ransac_kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor | None = None,
-                        threshold: float = 0.05, iterations: int = 1000, seed: int = 0, want_mask: bool = False):
-    """(B,N,3) float64 point sets -> T (B,4,4) f64, n_inliers (B) int32 [, inlier mask (B,N) bool]."""
+                        threshold: float = 0.05, iterations: int = 1000, seed: int = 0, want_mask: bool = False,
+                        first_pair: int = 0):
+    """(B,N,3) float64 point sets -> T (B,4,4) f64, n_inliers (B) int32 [, inlier mask (B,N) bool].
+    ``first_pair`` is item 0's pair index in the whole sequence: the hypothesis triples are keyed
+    on that global index, so chunking or sharding a sequence does not change its poses."""
     if P.dim() != 3 or P.shape[2] != 3 or Q.shape != P.shape:
         raise ValueError("Input arrays must be of shape (N, 3)")
     B, N, _ = P.shape
@@ -786,5 +789,5 @@ def ransac_kabsch_batch(P: torch.Tensor, Q: torch.Tensor, weight: torch.Tensor |
     mask = torch.empty((B, N), device=P.device, dtype=torch.uint8) if want_mask else None
     _call("vo_ransac_kabsch_batch", _dev(P, "P", torch.float64), _dev(Q, "Q", torch.float64),
           _opt(weight, "weight", torch.uint8), float(threshold), int(iterations), int(seed) & (2 ** 64 - 1),
-          T.data_ptr(), n_inl.data_ptr(), 0 if mask is None else mask.data_ptr(), B, N, _stream())
+          T.data_ptr(), n_inl.data_ptr(), 0 if mask is None else mask.data_ptr(), B, N, int(first_pair), _stream())
     return (T, n_inl, mask.bool()) if want_mask else (T, n_inl)

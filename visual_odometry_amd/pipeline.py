@@ -96,12 +96,14 @@ class VisualOdometry:
         """(F,H,W) gray GPU frames -> (F-1,2,H,W) flow between consecutive frames."""
         return self.flow_solver.compute_flow_sequence(left)
 
-    def poses(self, depth: torch.Tensor, flow: torch.Tensor):
-        """(F,H,W) depth + (F-1,2,H,W) flow -> T_rel (F-1,4,4) f64, skipped (F-1) bool."""
+    def poses(self, depth: torch.Tensor, flow: torch.Tensor, first_pair: int = 0):
+        """(F,H,W) depth + (F-1,2,H,W) flow -> T_rel (F-1,4,4) f64, skipped (F-1) bool.
+        ``first_pair``: index of pair 0 in the whole sequence (the RANSAC estimator keys its
+        hypothesis triples on the global pair index; the Kabsch fit ignores it)."""
         c = self.cfg
         P1, P2, wgt, n_in = self.pts_flow.pair_correspondences_batch(
             self.keypoints, depth[:-1], depth[1:], flow, c.min_depth, c.max_depth, c.max_dz)
-        T, n_used = self.cam_estimator.compute_camera_xform_batch(P1, P2, wgt)
+        T, n_used = self.cam_estimator.compute_camera_xform_batch(P1, P2, wgt, first_pair=first_pair)
         # the reference skips a pair when fewer than 4 points survive the range filter;
         # a pair whose final selection is empty has no pose at all (NaN from Kabsch, an
         # exception from RANSAC, flagged -1 here) and is skipped too
@@ -110,10 +112,12 @@ class VisualOdometry:
 
     # -- chunk / sequence --------------------------------------------------
     @torch.no_grad()
-    def process_chunk(self, left: torch.Tensor, right: torch.Tensor, first_depth: Optional[torch.Tensor] = None):
+    def process_chunk(self, left: torch.Tensor, right: torch.Tensor, first_depth: Optional[torch.Tensor] = None,
+                      first_pair: int = 0):
         """F consecutive frames -> (T_rel (F-1,4,4), skipped (F-1), depth of the last
         frame).  ``first_depth`` is the cached depth of frame 0 (the previous chunk's
-        last frame); without it frame 0's stereo pair is evaluated too."""
+        last frame); without it frame 0's stereo pair is evaluated too.  ``first_pair`` is
+        the sequence index of the chunk's first pair."""
         if left.shape[0] < 2:
             raise ValueError("a chunk needs at least two frames")
         if self.rectification is not None:
@@ -123,19 +127,61 @@ class VisualOdometry:
         else:
             depth = torch.cat([first_depth[None], self.depth_maps(left[1:], right[1:])], dim=0)
         flow = self.flows(left)
-        T, skipped = self.poses(depth, flow)
+        T, skipped = self.poses(depth, flow, first_pair)
         return T, skipped, depth[-1]
 
     @torch.no_grad()
-    def run(self, left: torch.Tensor, right: torch.Tensor, chunk_pairs: int = 8):
-        """Whole (F,H,W) uint8 GPU sequence -> (T_rel (F-1,4,4), skipped (F-1)) on the GPU."""
+    def run(self, left: torch.Tensor, right: torch.Tensor, chunk_pairs: int = 8, first_pair: int = 0):
+        """Whole (F,H,W) uint8 sequence -> (T_rel (F-1,4,4), skipped (F-1)) on the GPU, a chunk
+        of ``chunk_pairs`` pairs at a time with the last frame's depth carried over
+        (test_camera_tracking.py:143-150).  ``first_pair``: sequence index of frame 0 when the
+        frames are a shard of a longer sequence.
+
+        Frames on the GPU are sliced in place.  HOST frames (ideally pinned) are uploaded a
+        chunk at a time on a second stream, chunk k+1 while chunk k computes -- the
+        reference pays one blocking upload and one download per call
+        (flow/flow_map_RAFT.py:85,104-106); here the only download is the poses."""
         F = left.shape[0]
+        if F < 2:
+            z = torch.zeros((0, 4, 4), dtype=torch.float64, device=self.device)
+            return z, torch.zeros((0,), dtype=torch.bool, device=self.device)
+        bounds = [(s, min(s + chunk_pairs, F - 1)) for s in range(0, F - 1, chunk_pairs)]
+        on_host = not left.is_cuda
+        if on_host:
+            copy_stream = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream(self.device)
+
+            def upload(s, e):
+                with torch.cuda.stream(copy_stream):
+                    l = left[s:e + 1].to(self.device, non_blocking=True)
+                    r = right[s:e + 1].to(self.device, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(copy_stream)
+                return l, r, done
+            pending = upload(*bounds[0])
         Ts, sk, cached = [], [], None
-        for s in range(0, F - 1, chunk_pairs):
-            e = min(s + chunk_pairs, F - 1)
-            T, k, cached = self.process_chunk(left[s:e + 1], right[s:e + 1], cached)
+        for i, (s, e) in enumerate(bounds):
+            if on_host:
+                l, r, done = pending
+                main.wait_event(done)
+                l.record_stream(main); r.record_stream(main)      # allocated on the copy stream, used on this one
+                if i + 1 < len(bounds):
+                    pending = upload(*bounds[i + 1])
+            else:
+                l, r = left[s:e + 1], right[s:e + 1]
+            T, k, cached = self.process_chunk(l, r, cached, first_pair + s)
             Ts.append(T); sk.append(k)
         return torch.cat(Ts), torch.cat(sk)
+
+    @torch.no_grad()
+    def run_shard(self, left, right, rank: int, world: int, chunk_pairs: int = 8):
+        """This rank's contiguous block of the sequence's pairs: see ``run_shard``."""
+        return run_shard(self.run, left, right, rank, world, chunk_pairs)
+
+    @torch.no_grad()
+    def run_sharded(self, left, right, chunk_pairs: int = 8, group=None):
+        """The whole tracking loop over all ranks of ``group``: see ``run_sharded``."""
+        return run_sharded(self.run, left, right, chunk_pairs, group)
 
 
     @torch.no_grad()
@@ -174,18 +220,56 @@ def shard_pairs(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
     return start, min(start + per, n_pairs)
 
 
+def run_shard(run, left, right, rank: int, world: int, chunk_pairs: int = 8):
+    """Rank ``rank``'s contiguous block of the sequence's pairs (shard_pairs): frames
+    start..end inclusive -- the first one is the halo frame whose depth the rank
+    recomputes, as the reference does for the first frame it sees
+    (test_camera_tracking.py:136-139).  ``left`` / ``right`` hold the WHOLE sequence (host
+    or GPU tensors; only the shard's frames are touched); ``run`` is
+    ``VisualOdometry.run`` (frames, frames, chunk_pairs, first_pair=) -> (T_rel, skipped).
+    Returns (start, end, T_rel (end-start,4,4), skipped (end-start))."""
+    n_pairs = left.shape[0] - 1
+    start, end = shard_pairs(n_pairs, rank, world)
+    if end == start:                      # more ranks than pairs: an empty block still joins the gather
+        T, sk = run(left[:0], right[:0], chunk_pairs, first_pair=start)
+    else:
+        T, sk = run(left[start:end + 1], right[start:end + 1], chunk_pairs, first_pair=start)
+    return start, end, T, sk
+
+
+def run_sharded(run, left, right, chunk_pairs: int = 8, group=None):
+    """The whole tracking loop over all ranks of ``group`` (one process per GPU): every
+    rank runs its shard, the relative poses are all-gathered (RCCL with the nccl backend)
+    and every rank composes the same trajectory on the host in float64, in pair order,
+    skipped pairs contributing nothing (test_camera_tracking.py:188-190,205-210).  Without
+    an initialised process group this is the single-GPU loop.
+    Returns host arrays (T_rel (n,4,4), skipped (n), T_global (n,4,4))."""
+    import torch.distributed as dist
+    live = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if live else 0
+    world = dist.get_world_size(group) if live else 1
+    n_pairs = left.shape[0] - 1
+    _, _, T, sk = run_shard(run, left, right, rank, world, chunk_pairs)
+    T_rel, skipped = gather_poses(T, sk, n_pairs, group)
+    return T_rel, skipped, compose_trajectory(T_rel, skipped)
+
+
 def gather_poses(T_local: torch.Tensor, skipped_local: torch.Tensor, n_pairs: int, group=None):
     """All-gather the per-rank (k,4,4) float64 relative poses and skip flags into
     the full (n_pairs,4,4) / (n_pairs,) arrays on the host, in pair order.  Blocks
     are padded to ceil(n/world) so one equal-sized all_gather suffices (RCCL over
     xGMI with the nccl backend; gloo works the same for CPU tensors)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return T_local.cpu().numpy(), skipped_local.cpu().numpy().astype(bool)
     world = dist.get_world_size(group)
     per = -(-n_pairs // world)
-    payload = torch.zeros((per, 17), dtype=torch.float64, device=T_local.device)
+    # the collective runs where the backend works: device memory for nccl (RCCL), host memory for gloo
+    dev = T_local.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    payload = torch.zeros((per, 17), dtype=torch.float64, device=dev)
     k = T_local.shape[0]
+    if k > per:
+        raise ValueError(f"this rank holds {k} pairs, more than its block of {per}")
     payload[:k, :16] = T_local.reshape(k, 16)
     payload[:k, 16] = skipped_local.to(torch.float64)
     payload[k:, 16] = 1.0                                   # padding rows count as skipped
