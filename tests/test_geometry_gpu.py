@@ -213,6 +213,8 @@ def test_ransac_matches_oracle_with_same_triples(vo):
             np.testing.assert_allclose(T[b, :3, 3], tr, atol=1e-9)
             assert rot_angle(T[b, :3, :3], truth[b][0]) < 5e-3          # outliers rejected
             assert mask[b].sum() == n_inl[b] and not mask[b][~sel].any()
+            err = np.linalg.norm(P[b] @ T[b, :3, :3].T + T[b, :3, 3] - Q[b], axis=1)
+            assert n_inl[b] > 0.6 * sel.sum() and np.median(err[mask[b]]) < 0.02
     # the triples are keyed on the pair's index in the SEQUENCE: items 2.. of the batch handed
     # over as a batch of their own with first_pair=2 (and 2 + 2^32, the index is taken modulo
     # 2^32) reproduce the same poses bit for bit, and match the oracle fed the global index
@@ -227,8 +229,6 @@ def test_ransac_matches_oracle_with_same_triples(vo):
     np.testing.assert_allclose(T_off[0, :3, 3].cpu().numpy(), tr, atol=1e-9)
     with pytest.raises(ValueError):
         ops.ransac_kabsch_batch(Pd, Qd, None, 0.05, 10, first_pair=-1)
-            err = np.linalg.norm(P[b] @ T[b, :3, :3].T + T[b, :3, 3] - Q[b], axis=1)
-            assert n_inl[b] > 0.6 * sel.sum() and np.median(err[mask[b]]) < 0.02
     # the drop-in class: same signature, same exceptions as the reference
     est = HipCameraRansacXform(threshold=0.05, iterations=200, seed=1234)
     R0, t0 = est.compute_camera_xform(P[0], Q[0])
