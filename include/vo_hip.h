@@ -356,6 +356,29 @@ int vo_kabsch_batch(const double* P, const double* Q, const uint8_t* weight,
                     int batch, int N, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * The geometry half of the tracking loop for a batch of frame pairs in ONE call --
+ * test_camera_tracking.py:176-210: vo_pair_correspondences -> vo_kabsch_batch ->
+ * skip flag, without the correspondences ever leaving the device.
+ * Inputs as vo_pair_correspondences plus offset_host (CameraSvdXform's offset, 3 doubles
+ * on the host or NULL) and min_points (:188, 4 in the driver).
+ * T_out: (B,4,4) float64; skipped_out: (B) uint8, 1 where fewer than min_points keypoints
+ * pass the depth-range filter (the reference's `continue`, :188-190) or no point survives
+ * all filters (T_out is then NaN, as CameraSvdXform returns for an empty set).
+ * workspace: DEVICE memory, 256-byte aligned, at least vo_pair_poses_workspace_bytes(B, N)
+ * bytes (P1, P2, weights and two counters per pair live there); contents on entry do not
+ * matter, contents on return are unspecified.  Calls sharing a workspace must be ordered
+ * on one stream.
+ * ------------------------------------------------------------------------- */
+int64_t vo_pair_poses_workspace_bytes(int batch, int N);
+int vo_pair_poses(const double* kp, int64_t kp_batch_stride,
+                  const float* depth1, const float* depth2, const float* flow,
+                  const double* Kinv_host, double min_depth, double max_depth, double max_dz,
+                  const double* offset_host, int min_points,
+                  double* T_out, uint8_t* skipped_out,
+                  void* workspace, int64_t workspace_bytes,
+                  int batch, int N, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------
  * CameraRansacXform.compute_camera_xform -- camera/camera_svd_xform.py:52-149,
  * batched: one 256-lane workgroup per pair, one 3-point hypothesis per lane per round.
  * P, Q: (B,N,3) float64, 3 <= N <= 65535; weight: (B,N) uint8 or NULL.

@@ -134,6 +134,46 @@ def test_pair_correspondences_batch(vo):
     assert int(w0.sum()) == 0 and int(n0.sum()) == 0
 
 
+def test_pair_poses_one_call_equals_the_staged_path_and_the_reference_trace(vo):
+    """vo_pair_poses (correspondences in a caller workspace) against the reference's 8-pair trace
+    and, bit for bit, against vo_pair_correspondences + vo_kabsch_batch; skip flags for an empty
+    depth range; a workspace that is too small or misaligned is rejected."""
+    from visual_odometry_amd import _lib, ops
+    g = golden("g7_trace")
+    pairs = cases.trace_case()
+    K_inv = np.linalg.inv(cases.K_for(640))
+    kp = ref.uniform_keypoints(np.ones((480, 640), bool), 320)
+    dev = torch.device("cuda")
+    d1 = torch.from_numpy(np.stack([p["depth1"] for p in pairs])).to(dev)
+    d2 = torch.from_numpy(np.stack([p["depth2"] for p in pairs])).to(dev)
+    fl = torch.from_numpy(np.stack([p["flow"] for p in pairs])).to(dev)
+    kpd = torch.from_numpy(kp.astype(np.float64)).to(dev)
+    T, skipped, ws = ops.pair_poses(kpd, d1, d2, fl, K_inv, offset=syn.CAMERA_OFFSET)
+    assert not bool(skipped.any()) and ws.numel() == _lib.load().vo_pair_poses_workspace_bytes(len(pairs), kp.shape[0])
+    np.testing.assert_allclose(T.cpu().numpy(), g["T_rel"], atol=1e-9)
+    P1, P2, wgt, n_in = ops.pair_correspondences(kpd, d1, d2, fl, K_inv)
+    T2, _ = ops.kabsch_batch(P1, P2, wgt, syn.CAMERA_OFFSET)
+    assert torch.equal(T, T2)
+    # the workspace is reused (dirty) by a smaller second call
+    T3, sk3, ws3 = ops.pair_poses(kpd[:100].contiguous(), d1[:3], d2[:3], fl[:3], K_inv, offset=syn.CAMERA_OFFSET, workspace=ws)
+    assert ws3 is ws
+    P1, P2, wgt, n_in = ops.pair_correspondences(kpd[:100].contiguous(), d1[:3], d2[:3], fl[:3], K_inv)
+    assert torch.equal(T3, ops.kabsch_batch(P1, P2, wgt, syn.CAMERA_OFFSET)[0]) and not bool(sk3.any())
+    # nothing inside the depth range: every pair skipped (test_camera_tracking.py:188-190)
+    _, sk0, _ = ops.pair_poses(kpd, d1, d2, fl, K_inv, 100.0, 200.0, 1.0, workspace=ws)
+    assert bool(sk0.all())
+    # min_points counts the rows left by the range filter
+    _, skm, _ = ops.pair_poses(kpd, d1, d2, fl, K_inv, min_points=int(g["n_in_range"].max()) + 1, workspace=ws)
+    assert bool(skm.all())
+    small = torch.empty((1024,), dtype=torch.uint8, device=dev)
+    args = lambda w, n: ("vo_pair_poses", kpd.data_ptr(), 0, d1.data_ptr(), d2.data_ptr(), fl.data_ptr(), ops._host9(K_inv),
+                         0.0, 15.0, 1.0, None, 4, T.data_ptr(), skipped.data_ptr(), w, n, len(pairs), kp.shape[0], 480, 640, 0)
+    with pytest.raises(ValueError):
+        _lib.call(*args(small.data_ptr(), small.numel()))
+    with pytest.raises(ValueError):
+        _lib.call(*args(ws.data_ptr() + 8, ws.numel() - 8))
+
+
 def test_kabsch_cases_and_batch(vo):
     from visual_odometry_amd import ops
     from visual_odometry_amd.geometry import HipCameraSvdXform

@@ -147,6 +147,23 @@ def test_run_sharded_through_a_single_rank_rccl_group(vo):
     np.testing.assert_allclose(G1, want, atol=1e-6)
 
 
+def test_full_args_chunk_invariance_at_full_size(vo):
+    """The reference's default RAFT-Stereo arguments (stereo/stereo_disparity_RAFT.py:33-44) at
+    640x480, 12 iterations: 8 frame pairs as one chunk and as ragged chunks of 3, 3 and 2."""
+    from visual_odometry_amd.raft.models import RAFTStereoConfig
+    H, W, F = 480, 640, 9
+    pipe = _vo(H, W, iters=12, n_kp=320, stereo=RAFTStereoConfig())
+    assert pipe.disparity_solver.model.cfg.n_gru_layers == 3 and pipe.disparity_solver.model.cfg.hidden_dims == [128] * 3
+    left, right = syn.stereo_sequence(29, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    T_all, sk_all = pipe.run(l, r, chunk_pairs=F - 1)
+    T_chunks, sk_chunks = pipe.run(l, r, chunk_pairs=3)
+    assert torch.equal(sk_all, sk_chunks)
+    ok = ~sk_all
+    assert int(ok.sum()) > 0
+    assert (T_all[ok] - T_chunks[ok]).abs().max().item() < 1e-6
+
+
 def test_recovers_known_motion_from_exact_maps(vo):
     """Planar scenes with exact depth/flow: the pose kernel chain recovers the
     synthetic camera motion (accuracy is limited by the truncated-pixel depth

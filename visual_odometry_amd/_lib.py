@@ -60,9 +60,12 @@ SIGNATURES = {
     "vo_keypoints_to_2d": [_P, _P, _P, _P, _L, _P],
     "vo_track_keypoints": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "vo_kabsch_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vo_pair_poses": [_P, _L, _P, _P, _P, _P, _D, _D, _D, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "vo_ransac_kabsch_batch": [_P, _P, _P, _D, _I, c_uint64, _P, _P, _P, _I, _I, _L, _P],
 }
-EXPORTS = sorted(list(SIGNATURES) + ["vo_version", "vo_last_error"])
+# entry points that return a size instead of a status
+SIZE_QUERIES = {"vo_pair_poses_workspace_bytes": [_I, _I]}
+EXPORTS = sorted(list(SIGNATURES) + list(SIZE_QUERIES) + ["vo_version", "vo_last_error"])
 
 _lib = None
 
@@ -84,6 +87,10 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = c_int
+    for name, args in SIZE_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int64
     lib.vo_version.argtypes = []
     lib.vo_version.restype = c_int
     lib.vo_last_error.argtypes = []

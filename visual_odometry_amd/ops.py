@@ -712,6 +712,30 @@ def pair_correspondences(kp, depth1, depth2, flow, K_inv, min_depth=0.0, max_dep
     return p1, p2, wgt, n_in
 
 
+def pair_poses(kp, depth1, depth2, flow, K_inv, min_depth=0.0, max_depth=15.0, max_dz=1.0, offset=None,
+               min_points: int = 4, workspace: torch.Tensor | None = None):
+    """The geometry half of the tracking loop in one call: grid keypoints + depth maps (B,H,W) + flow
+    (B,2,H,W) -> T (B,4,4) float64, skipped (B) bool.  ``workspace`` (optional uint8 GPU tensor,
+    reused across calls when it is large enough) holds the correspondences; returns it third."""
+    B, H, W = _check_maps(depth1, depth2, flow)
+    p, stride, N = _kp_args(kp, B)
+    if N < 1:
+        raise ValueError("pair_poses needs at least one keypoint")
+    need = int(_lib.load().vo_pair_poses_workspace_bytes(B, N))
+    if workspace is None or workspace.numel() < need or workspace.device != flow.device:
+        workspace = torch.empty((need,), device=flow.device, dtype=torch.uint8)
+    T = torch.empty((B, 4, 4), device=flow.device, dtype=torch.float64)
+    skipped = torch.empty((B,), device=flow.device, dtype=torch.uint8)
+    off = None
+    if offset is not None:
+        off = _host_doubles(offset, 3, "offset")
+    _call("vo_pair_poses", p, stride, _dev(depth1, "depth1", torch.float32), _dev(depth2, "depth2", torch.float32),
+          _dev(flow, "flow", torch.float32), _host9(K_inv), float(min_depth), float(max_depth), float(max_dz), off,
+          int(min_points), T.data_ptr(), skipped.data_ptr(), _dev(workspace, "workspace", torch.uint8),
+          workspace.numel(), B, N, H, W, _stream(), nbytes=B * N * (16 + 8 + 8 + 2 * 49) + B * 129)
+    return T, skipped.bool(), workspace
+
+
 def keypoints_to_2d(points: torch.Tensor, K):
     """(..., 3) float64 camera-space points -> (uv (..., 2) float64, keep (...) bool); keep is
     False where Z <= 0 (rows the reference's to_2d drops)."""

@@ -85,6 +85,7 @@ class VisualOdometry:
             raise ValueError("VOConfig.pose must be 'svd' or 'ransac'")
         self.keypoints = self.pts_src.get_keypoints_device(cfg.max_keypoints)
         self._cam = cam
+        self._pose_ws = None
 
     # -- stages ------------------------------------------------------------
     def depth_maps(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
@@ -101,6 +102,13 @@ class VisualOdometry:
         ``first_pair``: index of pair 0 in the whole sequence (the RANSAC estimator keys its
         hypothesis triples on the global pair index; the Kabsch fit ignores it)."""
         c = self.cfg
+        if c.pose == "svd":
+            # correspondences -> Kabsch -> skip flag in one call, the correspondences staying in a
+            # workspace that is kept across chunks
+            T, skipped, self._pose_ws = ops.pair_poses(
+                self.keypoints, depth[:-1], depth[1:], flow, self.pts_xform.K_inv, c.min_depth, c.max_depth,
+                c.max_dz, self.cam_estimator.offset, c.min_points, self._pose_ws)
+            return T, skipped
         P1, P2, wgt, n_in = self.pts_flow.pair_correspondences_batch(
             self.keypoints, depth[:-1], depth[1:], flow, c.min_depth, c.max_depth, c.max_dz)
         T, n_used = self.cam_estimator.compute_camera_xform_batch(P1, P2, wgt, first_pair=first_pair)
