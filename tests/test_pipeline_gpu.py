@@ -120,7 +120,7 @@ def test_host_frames_are_uploaded_chunk_by_chunk(vo):
     T_host, sk_host = pipe.run(lh, rh, chunk_pairs=3)
     assert T_host.is_cuda and torch.equal(sk_dev, sk_host)
     err = (T_host[~sk_host] - T_dev[~sk_dev]).abs().max().item()
-    assert err < 1e-6, err                      # same chunks, same kernels: only the atomics' order differs
+    assert err < 1e-4, err      # same chunks; run-to-run rounding of the small-map MIOpen layers and the atomics' order
 
 
 def test_run_sharded_through_a_single_rank_rccl_group(vo):
@@ -137,7 +137,7 @@ def test_run_sharded_through_a_single_rank_rccl_group(vo):
     want = compose_trajectory(T.cpu().numpy(), sk.cpu().numpy())
     # without a process group: the single-GPU loop
     T0, s0, G0 = pipe.run_sharded(l, r, chunk_pairs=3)
-    assert np.abs(G0 - want).max() < 1e-5
+    assert np.abs(G0 - want).max() < 1e-3
     assert not dist.is_initialized()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
@@ -147,8 +147,8 @@ def test_run_sharded_through_a_single_rank_rccl_group(vo):
     finally:
         dist.destroy_process_group()
     assert T1.shape == (F - 1, 4, 4) and np.array_equal(s1, sk.cpu().numpy())
-    assert np.abs(T1[~s1] - T.cpu().numpy()[~s1]).max() < 1e-6
-    assert np.abs(G1 - want).max() < 1e-5
+    assert np.abs(T1[~s1] - T.cpu().numpy()[~s1]).max() < 1e-4
+    assert np.abs(G1 - want).max() < 1e-3
 
 
 def test_full_args_chunk_invariance_at_full_size(vo):
