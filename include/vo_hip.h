@@ -378,6 +378,25 @@ int vo_pair_poses(const double* kp, int64_t kp_batch_stride,
                   void* workspace, int64_t workspace_bytes,
                   int batch, int N, int H, int W, void* stream);
 
+/* vo_pair_poses without the workspace argument: the correspondences live in a fixed array
+ * inside the library, so the call allocates nothing and needs nothing allocated for it.
+ * It has NO counterpart in the reference; it exists for callers that cannot allocate
+ * device memory around the call -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Arguments and results exactly as vo_pair_poses.
+ * Limits: batch <= VO_PAIR_POSES_STATIC_MAX_BATCH and batch*N <=
+ * VO_PAIR_POSES_STATIC_MAX_POINTS (VO_ERR_UNSUPPORTED beyond; use vo_pair_poses then).
+ * The array (about 12.4 MiB) exists once per GPU the library runs on, for the life of the
+ * process, and is shared by every call on that GPU: calls that overlap in time on one GPU
+ * (different streams or threads) race on it -- order them on one stream. */
+#define VO_PAIR_POSES_STATIC_MAX_BATCH  8192
+#define VO_PAIR_POSES_STATIC_MAX_POINTS 262144
+int vo_pair_poses_static(const double* kp, int64_t kp_batch_stride,
+                         const float* depth1, const float* depth2, const float* flow,
+                         const double* Kinv_host, double min_depth, double max_depth, double max_dz,
+                         const double* offset_host, int min_points,
+                         double* T_out, uint8_t* skipped_out,
+                         int batch, int N, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------------------
  * CameraRansacXform.compute_camera_xform -- camera/camera_svd_xform.py:52-149,
  * batched: one 256-lane workgroup per pair, one 3-point hypothesis per lane per round.

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vo_track_keypoints": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "vo_kabsch_batch": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vo_pair_poses": [_P, _L, _P, _P, _P, _P, _D, _D, _D, _P, _I, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "vo_pair_poses_static": [_P, _L, _P, _P, _P, _P, _D, _D, _D, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "vo_ransac_kabsch_batch": [_P, _P, _P, _D, _I, c_uint64, _P, _P, _P, _I, _I, _L, _P],
 }
 # entry points that return a size instead of a status
