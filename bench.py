@@ -110,35 +110,126 @@ def mixed_precision_leg(vo32, vo16, left, right, cached, steps):
             "note": "not the reference's precision (mixed_precision=False there); reported beside, not as, the metric"}
 
 
-def cpu_baseline(vo, left, right, iters, cores):
-    """Time the CPU oracle on ONE frame pair of the same workload (1 stereo frame +
-    1 flow pair + geometry), using ``cores`` host threads."""
+def _time(fn, repeat):
+    fn()                                   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(repeat):
+        fn()
+    return (time.perf_counter() - t0) / repeat
+
+
+def cpu_baseline(vo, left, right, iters, threads, stereo_name):
+    """The CPU oracle (kind "port": stock-PyTorch RAFT restatement + NumPy geometry) on this box's
+    host cores, on a bounded sample of the same workload.  The headline figure is one steady-state
+    frame pair (1 new stereo frame + 1 flow pair + geometry with the reference's per-point loop)
+    with ``threads`` threads, averaged over 3 pairs after a warm-up; beside it the single-thread
+    figure and the geometry / pose / composition stages on their own."""
     from oracle import geometry_ref, raft_ref
-    torch.set_num_threads(cores)
     flow_m = copy.deepcopy(vo.flow_solver.model).cpu().eval()
     stereo_m = copy.deepcopy(vo.disparity_solver.model).cpu().eval()
     rgb = lambda a: a.float()[:, None].expand(-1, 3, -1, -1).contiguous().cpu()
-    l, r = rgb(left[:2]), rgb(right[:2])
-    small = torch.rand(1, 3, 64, 96) * 255                       # thread-pool / allocator warm-up
-    raft_ref.raft_flow_forward(flow_m, small, small, 1)
-    raft_ref.raft_stereo_forward(stereo_m, small, small, 1)
+    n_pairs = 3
+    l, r = rgb(left[:n_pairs + 1]), rgb(right[:n_pairs + 1])
+    small = torch.rand(1, 3, 64, 96) * 255
     K_inv = vo.pts_xform.K_inv
     kp = vo.pts_src.get_keypoints(None, vo.cfg.max_keypoints)
+    H, W = left.shape[1:]
+
+    def networks(n):
+        """n steady-state pairs: stereo on frames 1..n, flow on pairs (0,1)..(n-1,n)."""
+        t0 = time.perf_counter()
+        _, disp = raft_ref.raft_stereo_forward(stereo_m, l[1:n + 1], r[1:n + 1], iters)
+        t1 = time.perf_counter()
+        _, flow = raft_ref.raft_flow_forward(flow_m, l[:n], l[1:n + 1], iters)
+        return t1 - t0, time.perf_counter() - t1, disp, flow
+
+    torch.set_num_threads(threads)
+    raft_ref.raft_flow_forward(flow_m, small, small, 1)              # thread-pool / allocator warm-up
+    raft_ref.raft_stereo_forward(stereo_m, small, small, 1)
+    networks(1)
+    ts, tf, disp, flow = networks(n_pairs)
+    t_stereo, t_flow = ts / n_pairs, tf / n_pairs
+    depth = [geometry_ref.disparity_to_depth(disp[i, 0].numpy(), vo._fxB, 1.0) for i in range(n_pairs)]
+    flow_np = flow.numpy()
+    geo = lambda loop: geometry_ref.pair_pose(kp, depth[0], depth[1], flow_np[1], K_inv, loop=loop)
+    t_geo_loop = _time(lambda: (geometry_ref.disparity_to_depth(disp[1, 0].numpy(), vo._fxB, 1.0), geo(True)), 5)
+    t_geo_vec = _time(lambda: (geometry_ref.disparity_to_depth(disp[1, 0].numpy(), vo._fxB, 1.0), geo(False)), 20)
+    per_pair = t_stereo + t_flow + t_geo_loop
+
+    torch.set_num_threads(1)
+    ts1, tf1, _, _ = networks(1)
+    torch.set_num_threads(threads)
+    per_pair_1 = ts1 + tf1 + t_geo_loop
+
+    # the dense 1280x720 grid (19 928 points): geometry only, synthetic maps
+    rng = np.random.default_rng(0)
+    Hd, Wd = 720, 1280
+    kpd = geometry_ref.uniform_keypoints(np.ones((Hd, Wd), bool), 20000)
+    d1 = rng.uniform(0.5, 12, (Hd, Wd)).astype(np.float32); d2 = d1 + rng.normal(0, 0.05, d1.shape).astype(np.float32)
+    fl = rng.normal(0, 2, (2, Hd, Wd)).astype(np.float32)
+    Kd = np.linalg.inv(np.array([[556.0, 0, 640], [0, 556.0, 360], [0, 0, 1]]))
+    t_dense_loop = _time(lambda: geometry_ref.pair_pose(kpd, d1, d2, fl, Kd, loop=True), 1)
+    t_dense_vec = _time(lambda: geometry_ref.pair_pose(kpd, d1, d2, fl, Kd, loop=False), 5)
+    # Kabsch alone (numpy.linalg.svd per pair, camera/camera_svd_xform.py:31)
+    P = rng.uniform(-3, 3, (256, 300, 3)); Q = P + rng.normal(0, 0.01, P.shape)
+    t_kabsch_300 = _time(lambda: [geometry_ref.kabsch(P[b], Q[b]) for b in range(256)], 2) / 256
+    Pd = rng.uniform(-3, 3, (8, 19928, 3)); Qd = Pd + rng.normal(0, 0.01, Pd.shape)
+    t_kabsch_dense = _time(lambda: [geometry_ref.kabsch(Pd[b], Qd[b]) for b in range(8)], 2) / 8
+    # host composition of 100 000 relative poses (test_camera_tracking.py:210)
+    Tn = np.tile(np.eye(4), (100000, 1, 1))
+    t_compose = _time(lambda: geometry_ref.compose_trajectory(Tn), 1)
+    return {"value": 1.0 / per_pair, "unit": "frame-pairs/s", "cores": threads, "host_cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{n_pairs} steady-state frame pairs {W}x{H} after one warm-up pair, {iters} iters: "
+                      f"RAFT-Stereo({stereo_name} args) {t_stereo:.2f}s + RAFT-Flow {t_flow:.2f}s + "
+                      f"geometry (per-point loop) {t_geo_loop * 1e3:.1f}ms per pair, {threads} threads",
+            "seconds_per_pair": per_pair,
+            "single_thread": {"value": 1.0 / per_pair_1, "unit": "frame-pairs/s", "cores": 1,
+                              "sample": f"1 frame pair: RAFT-Stereo {ts1:.1f}s + RAFT-Flow {tf1:.1f}s + geometry"},
+            "geometry_us_per_pair": {"loop_300pts": 1e6 * t_geo_loop, "vectorised_300pts": 1e6 * t_geo_vec,
+                                     "loop_19928pts": 1e6 * t_dense_loop, "vectorised_19928pts": 1e6 * t_dense_vec},
+            "kabsch_pairs_per_s": {"n300": 1.0 / t_kabsch_300, "n19928": 1.0 / t_kabsch_dense},
+            "compose_100k_poses_ms": 1e3 * t_compose}
+
+
+def timed_steps(vo, left, right, cached, steps, warmup):
+    for _ in range(warmup):
+        vo.process_chunk(left, right, cached)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _, disp = raft_ref.raft_stereo_forward(stereo_m, l, r, iters)          # both frames (depth1, depth2)
-    t_stereo = (time.perf_counter() - t0) / 2                                # steady state: one new frame per pair
-    t1 = time.perf_counter()
-    _, flow = raft_ref.raft_flow_forward(flow_m, l[:1], l[1:2], iters)
-    t_flow = time.perf_counter() - t1
-    t2 = time.perf_counter()
-    depth = [geometry_ref.disparity_to_depth(disp[i, 0].numpy(), vo._fxB, 1.0) for i in range(2)]
-    geometry_ref.pair_pose(kp, depth[0], depth[1], flow[0].numpy(), K_inv, loop=True)
-    t_geo = (time.perf_counter() - t2)
-    per_pair = t_stereo + t_flow + t_geo
-    return {"value": 1.0 / per_pair, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 frame pair 640x480, {iters} iters: RAFT-Stereo(realtime) {t_stereo:.2f}s + RAFT-Flow "
-                      f"{t_flow:.2f}s + geometry (per-point loop) {t_geo * 1e3:.1f}ms",
-            "seconds_per_pair": per_pair}
+    for _ in range(steps):
+        vo.process_chunk(left, right, cached)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def config_leg(make, left, right, steps, what):
+    """A secondary measurement of the same step with another configuration of the reference
+    (never the headline): build the pipeline, first chunk untimed (halo depth), then time."""
+    vo2 = make()
+    B = left.shape[0] - 1
+    _, _, cached = vo2.process_chunk(left, right, None)
+    dt = timed_steps(vo2, left, right, cached, steps, 1)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    del vo2, cached
+    torch.cuda.empty_cache()
+    return {"value": B / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt, "pairs_per_step": B, "steps": steps,
+            "dtype": "f32", "config": what, "peak_device_memory_GiB": peak}
+
+
+def mfma_util_from_profile(kernel_key, B, H, W):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE / 8) of the committed counter pass, or
+    None when the pass was taken at another shape."""
+    for name in ("mfma_util.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        meta = json.load(open(path))
+        k = meta.get("kernels", {}).get(kernel_key)
+        if k and (meta.get("height"), meta.get("width")) == (H, W) and "mfma_busy_frac" in k:
+            return {"value": k["mfma_busy_frac"], "batch_pairs_of_the_pass": meta.get("batch_pairs"),
+                    "source": "profiles/" + name}
+    return None
 
 
 def main():
@@ -159,6 +250,9 @@ def main():
                     help="time the float16-activation path as the headline instead of float32 (not the reference's precision)")
     ap.add_argument("--no-mixed-precision-leg", action="store_true",
                     help="skip the secondary float16-activation measurement")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the secondary measurements of the reference's default (full) argument set")
+    ap.add_argument("--pose", choices=["svd", "ransac"], default="svd")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,10 +272,10 @@ def main():
 
     H, W, B = args.height, args.width, args.batch
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
-    def make_vo(mixed):
-        cfg = VOConfig(iters=args.iters,
-                       stereo=RAFTStereoConfig.realtime() if args.stereo == "realtime" else RAFTStereoConfig(),
-                       camera_offset=syn.CAMERA_OFFSET, mixed_precision=mixed)
+    def make_vo(mixed, stereo=args.stereo, iters=args.iters, pose=args.pose):
+        cfg = VOConfig(iters=iters,
+                       stereo=RAFTStereoConfig.realtime() if stereo == "realtime" else RAFTStereoConfig(),
+                       camera_offset=syn.CAMERA_OFFSET, mixed_precision=mixed, pose=pose)
         return VisualOdometry(cfg, syn.left_K(W / 640.0), syn.focal_length_px() * (W / 640.0), syn.baseline(),
                               np.ones((H, W), bool), seed=0)
 
@@ -224,6 +318,21 @@ def main():
 
     pairs = world * B * args.steps
     value = pairs / elapsed
+
+    # outside the timed region: the one exchange of the sharded loop, an all-gather of the ranks'
+    # relative poses (RCCL when launched by torch.distributed.run), then the host composition
+    from visual_odometry_amd.pipeline import compose_trajectory, gather_poses
+    torch.cuda.synchronize()
+    t_g = time.perf_counter()
+    T_all, sk_all = gather_poses(T, skipped, world * B)
+    gather_ms = 1e3 * (time.perf_counter() - t_g)
+    t_c = time.perf_counter()
+    G = compose_trajectory(T_all, sk_all)
+    compose_ms = 1e3 * (time.perf_counter() - t_c)
+    gather = {"ranks": int(dist.get_world_size()) if dist is not None else 1,
+              "backend": dist.get_backend() if dist is not None else None,
+              "poses_gathered": int(T_all.shape[0]), "gather_ms": gather_ms, "compose_ms": compose_ms,
+              "trajectory_is_rigid": bool(np.abs(G[-1][:3, :3] @ G[-1][:3, :3].T - np.eye(3)).max() < 1e-9)}
 
     # per-kernel device time from the events recorded inside the timed region
     work = algorithmic_work(B, H, W, args.iters, n_kp)
@@ -271,7 +380,7 @@ def main():
         roofline_corr = {"kernel": "vo_corr_volume_2d", "bound": "mfma", "achieved": ck["TFLOPs"],
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ck["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
                          "avg_launch_us": ck["avg_us"], "traffic": pmc_traffic("vo_corr_volume_2d", B, H, W),
-                         "mfma_util_pmc": 0.695}   # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE/8), profiles/r01_mfma_util.json
+                         "mfma_util_pmc": mfma_util_from_profile("corr2d", B, H, W)}
     roofline["alg_per_launch"] = (work[dom].get("flops") if roofline["bound"] == "mfma" else work[dom]["bytes"]) / work[dom]["launches"]
     hand_ms = sum(k["ms_per_step"] for k in kernels.values())
 
@@ -283,9 +392,14 @@ def main():
             "vs_baseline": None, "dtype": "f16 activations, f32 weights/correlation/geometry" if args.mixed_precision else "f32",
             "data": "synthetic",
             "config": {"workload": f"RAFT-Flow + RAFT-Stereo({args.stereo} args) {W}x{H}, {args.iters} iters, "
-                                   f"{n_kp} grid keypoints, Kabsch pose; synthetic stereo frame pairs resident in HBM",
+                                   f"{n_kp} grid keypoints, {'Kabsch' if args.pose == 'svd' else 'RANSAC'} pose; "
+                                   f"synthetic stereo frame pairs resident in HBM",
                        "pairs_per_step_per_gpu": B, "pairs_timed": pairs, "iters": args.iters,
-                       "sharding": f"{world} rank(s), contiguous pair ranges, no data-path collective"},
+                       "sharding": f"{world} rank(s), contiguous pair ranges, no data-path collective",
+                       "conditions": f"the same {B + 1} frames per rank are re-used by every step and stay resident in "
+                                     f"HBM; the PCIe upload is outside value (with_upload reports it inside); no "
+                                     f"graph capture; pose gather + composition outside the timed region (gather)"},
+            "gather": gather,
             "roofline": roofline,
             "roofline_corr": roofline_corr,
             "hand_kernels_ms_per_step": hand_ms,
@@ -293,11 +407,40 @@ def main():
             "kernels": kernels,
             "skipped_pairs_last_step": int(skipped.sum().item()),
         }
+        if world == 1:
+            # the same step with the chunk's frames coming from pinned host memory, uploaded on a second
+            # stream one chunk ahead of the computation (what a caller holding host frames pays)
+            reps = max(2, min(args.steps, 4))
+            lh = left.cpu().repeat(reps, 1, 1)[: reps * B + 1].pin_memory()
+            rh = right.cpu().repeat(reps, 1, 1)[: reps * B + 1].pin_memory()
+            vo.run(lh[: B + 1], rh[: B + 1], chunk_pairs=B)
+            torch.cuda.synchronize()
+            t_u = time.perf_counter()
+            vo.run(lh, rh, chunk_pairs=B)
+            torch.cuda.synchronize()
+            dt_u = time.perf_counter() - t_u
+            # run() also evaluates the halo frame's stereo pair of the first chunk: one extra frame
+            out["with_upload"] = {"value": reps * B / dt_u, "unit": "frame-pairs/s", "pairs": reps * B,
+                                  "note": "frames from pinned host memory, chunk k+1 uploaded on a second stream "
+                                          "while chunk k computes; includes the first chunk's halo stereo frame"}
+            del lh, rh
         if world == 1 and not args.mixed_precision and not args.no_mixed_precision_leg:
             out["mixed_precision"] = mixed_precision_leg(vo, make_vo(True), left, right, cached, args.steps)
         if world == 1 and not args.no_cpu_baseline:
-            cores = args.cpu_cores or min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(vo, left, right, args.iters, cores)
+            threads = args.cpu_cores or torch.get_num_threads()
+            out["cpu_baseline"] = cpu_baseline(vo, left, right, args.iters, threads, args.stereo)
+        if world == 1 and not args.mixed_precision and not args.no_config_legs and args.stereo == "realtime":
+            legs_steps = max(1, min(args.steps, 3))
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            # BASELINE config 3: the argument set the reference hard-codes (stereo_disparity_RAFT.py:33-44)
+            out["full_args"] = config_leg(lambda: make_vo(False, "full", args.iters, "svd"), left, right, legs_steps,
+                                          f"RAFT-Flow + RAFT-Stereo(full args: hidden 128x3, 3 GRU levels) {W}x{H}, "
+                                          f"{args.iters} iters, Kabsch pose")
+            # what test_camera_tracking.py:66-82 itself runs: full args, iters=16, CameraRansacXform(0.05, 1000)
+            out["reference_driver_settings"] = config_leg(
+                lambda: make_vo(False, "full", 16, "ransac"), left, right, legs_steps,
+                f"RAFT-Flow + RAFT-Stereo(full args) {W}x{H}, 16 iters, RANSAC pose (1000 hypotheses per pair)")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
