@@ -144,6 +144,23 @@ int vo_conv3x3_winograd4(const float* x, const float* transformed, float* y, int
                          double* stats, const double* in_stats, float in_eps,
                          int N, int C, int H, int W, int K, void* stream);
 
+/* The same convolution (3x3, stride 1, padding 1, float32 in and out, NCHW) as a direct sum on
+ * the bf16 matrix cores with every float32 product assembled from bf16 pieces: x = xh + xl,
+ * w = wh + wl (high part = the value rounded to bf16, low part = the rounded rest), and
+ * x*w ~ xl*wh + xh*wl + xh*wh with float32 accumulation.  Each product keeps 16 significant bits;
+ * the largest error on the networks' layers is 4-6e-6 of the largest output (the F(4x4,3x3) kernel
+ * above: 1e-5).  Three bf16 matrix instructions per product still run at five times the rate of the
+ * float32 matrix instruction, which is why this is the default 3x3 kernel where it applies.
+ *   vo_conv3x3_bf16x3_filter  weight (K,C,3,3) float32 -> both bf16 parts in operand order,
+ *                             ceil(K/64)*64 * C * 9 * 4 BYTES.  C must be a multiple of 16.
+ *   vo_conv3x3_bf16x3         arguments, epilogue, statistics and normalise-on-load exactly as
+ *                             vo_conv3x3_winograd.  W must be even, x 8-byte aligned. */
+int vo_conv3x3_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
+                      const float* scale, const float* shift, int relu, const float* skip,
+                      double* stats, const double* in_stats, float in_eps,
+                      int N, int C, int H, int W, int K, void* stream);
+
 /* 1x5 (padding (0,2)) and 5x1 (padding (2,0)) stride-1 float32 convolutions, NCHW, no bias, as
  * one-dimensional Winograd F(4,5) on the matrix cores: the gate convolutions of the separable
  * GRU in RAFT's update block (model built at flow/flow_map_RAFT.py:42).

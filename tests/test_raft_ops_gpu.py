@@ -617,6 +617,120 @@ def test_kernels_write_channel_slices_in_place(vo, tile):
         ops.conv3x3_winograd(x, ops.winograd_filter(w, tile), K, out=wide.permute(0, 1, 3, 2)[:, :K])
 
 
+SPLIT_TOL = 2e-5                   # relative to the largest output value (measured 4-6e-6)
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(2, 16, 16, 32, 64), (1, 16, 37, 54, 40), (2, 64, 60, 80, 126), (1, 32, 17, 16, 32),
+                                       (3, 128, 33, 46, 192), (1, 16, 1, 2, 33), (2, 96, 30, 40, 96), (1, 48, 70, 100, 72),
+                                       (1, 256, 15, 20, 128), (5, 64, 120, 160, 64)])
+def test_split_bf16_conv3x3_matches_direct_convolution(vo, N, C, H, W, K):
+    """The split-bf16 direct 3x3 kernel (each float32 product from three bf16 matrix-core terms, float32
+    accumulation) against the float64 direct convolution: ragged image sizes, one-pixel-high and
+    two-pixel-wide maps, output channels that do not fill a 64-block (half blocks included), several
+    chunks of input channels, more tiles than workgroup slots, run-to-run identical results.
+    Tolerance 2e-5 of the largest output, the bar of the float32 F(2x2,3x3) kernel."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=50).to(DEV)
+    w = (_rand(K, C, 3, 3, seed=51) / (3 * C ** 0.5)).to(DEV)
+    U = ops.conv3x3_split_filter(w)
+    got = ops.conv3x3_winograd(x, U, K)
+    want = Fn.conv2d(x.double(), w.double(), None, 1, 1)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < SPLIT_TOL * max(1.0, want.abs().max().item())
+    assert torch.equal(got, ops.conv3x3_winograd(x, U, K))
+    # inputs spanning many binades: the split keeps 16 significant bits of EVERY product
+    xs = x * torch.exp2(torch.randint(-12, 12, x.shape, device=DEV).float())
+    gots = ops.conv3x3_winograd(xs, U, K)
+    wants = Fn.conv2d(xs.double(), w.double(), None, 1, 1)
+    assert (gots.double() - wants).abs().max().item() < SPLIT_TOL * max(1.0, wants.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.conv3x3_split_filter(_rand(8, 24, 3, 3, seed=1).to(DEV))           # channels not a multiple of 16
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(_rand(1, C, 8, 9, seed=2).to(DEV), U, K)          # odd width
+
+
+def test_split_bf16_conv3x3_epilogue_statistics_and_slices(vo):
+    """Fused epilogue (scale / shift / ReLU / residual join), plane statistics for a following instance
+    norm, normalise-on-load of the input and channel-slice output of the split-bf16 kernel, each against
+    stock operators; then a residual block with instance norm end to end on it."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    from visual_odometry_amd.raft import layers
+    N, C, H, W, K = 2, 32, 21, 28, 40
+    x, w = _rand(N, C, H, W, seed=70).to(DEV), (_rand(K, C, 3, 3, seed=71) / 12).to(DEV)
+    scale, shift, skip = _rand(K, seed=72).to(DEV), _rand(K, seed=73).to(DEV), _rand(N, K, H, W, seed=74).to(DEV)
+    U = ops.conv3x3_split_filter(w)
+    y = Fn.conv2d(x.double(), w.double(), None, 1, 1).float()
+    b = lambda v: v[None, :, None, None]
+    cases = [((None, shift, False, None), y + b(shift)), ((None, shift, True, None), torch.relu(y + b(shift))),
+             ((scale, shift, True, None), torch.relu(y * b(scale) + b(shift))),
+             ((scale, shift, True, skip), torch.relu(skip + torch.relu(y * b(scale) + b(shift)))),
+             ((None, None, True, skip), torch.relu(skip + torch.relu(y)))]
+    for args, want in cases:
+        got = ops.conv3x3_winograd(x, U, K, *args)
+        assert (got - want).abs().max().item() < SPLIT_TOL * max(1.0, want.abs().max().item())
+    wide = torch.full((N, 7 + K + 5, H, W), 3.25, device=DEV)
+    got = ops.conv3x3_winograd(x, U, K, None, shift, True, out=wide[:, 7:7 + K])
+    assert got.data_ptr() == wide[:, 7:7 + K].data_ptr()
+    assert (wide[:, 7:7 + K] - torch.relu(y + b(shift))).abs().max().item() < SPLIT_TOL * max(1.0, y.abs().max().item())
+    assert torch.all(wide[:, :7] == 3.25) and torch.all(wide[:, 7 + K:] == 3.25)
+    # statistics of the raw output -> one-pass instance norm (+ ReLU + residual join)
+    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (3, 64, 60, 80, 64), (1, 16, 16, 16, 33), (2, 96, 35, 66, 96)]:
+        x, w = _rand(N, C, H, W, seed=90).to(DEV), (_rand(K, C, 3, 3, seed=91) / 12).to(DEV)
+        skip = _rand(N, K, H, W, seed=92).to(DEV)
+        U = ops.conv3x3_split_filter(w)
+        stats = torch.zeros((N, K, 2), device=DEV, dtype=torch.float64)
+        yy = ops.conv3x3_winograd(x, U, K, stats=stats)
+        ref_y = Fn.conv2d(x.double(), w.double(), None, 1, 1)
+        want_stats = torch.stack([ref_y.sum((2, 3)), (ref_y * ref_y).sum((2, 3))], dim=2)
+        assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
+        want = torch.relu(skip + torch.relu(Fn.instance_norm(ref_y.float(), eps=1e-5)))
+        got = ops.instance_norm_apply_(yy, stats, 1e-5, True, skip)
+        assert (got - want).abs().max().item() < 5e-5
+    # the input normalised + ReLU-ed while it is staged
+    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (2, 64, 33, 46, 64), (1, 128, 30, 40, 128)]:
+        z = (_rand(N, C, H, W, seed=95, scale=2.0) + 0.7).to(DEV)
+        w = (_rand(K, C, 3, 3, seed=96) / 12).to(DEV)
+        st = torch.stack([z.double().sum((2, 3)), (z.double() ** 2).sum((2, 3))], dim=2).contiguous()
+        got = ops.conv3x3_winograd(z, ops.conv3x3_split_filter(w), K, in_stats=st, in_eps=1e-5)
+        want = Fn.conv2d(torch.relu(Fn.instance_norm(z.double(), eps=1e-5)), w.double(), None, 1, 1)
+        assert (got.double() - want).abs().max().item() < 1.5 * SPLIT_TOL * max(1.0, want.abs().max().item())
+    from visual_odometry_amd.raft.layers import ResidualBlock, fused_passes
+    torch.manual_seed(4)
+    blk = ResidualBlock(64, 64, "instance").to(DEV).eval()
+    xb = torch.relu(_rand(2, 64, 37, 52, seed=97)).to(DEV)
+    assert layers._winograd_tile_for(37, 52, 64) == 1               # the block does run on the split kernel
+    with torch.no_grad():
+        a = blk(xb)
+        with fused_passes():
+            bb = blk(xb)
+    assert (a - bb).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
+
+
+def test_networks_agree_across_conv_arithmetic(vo):
+    """Flow and disparity at 480x640 (every 3x3 layer large enough for the split-bf16 kernel) with the
+    float32-matrix-instruction kernels only against the default split-bf16 products, and each against
+    the stock-operator restatement: both inside the 0.05 px budget by three orders of magnitude."""
+    from visual_odometry_amd.raft import layers
+    from visual_odometry_amd.raft.models import RAFTFlow, RAFTStereo, RAFTStereoConfig
+    torch.manual_seed(12)
+    flow, stereo = RAFTFlow().to(DEV).eval(), RAFTStereo(RAFTStereoConfig.realtime()).to(DEV).eval()
+    left, right = _images(1, 480, 640, seed=8)
+    try:
+        layers.conv_arithmetic("f32")
+        f0, d0 = flow(left[:1], left[1:2], iters=6)[1], stereo(left[:1], right[:1], iters=6)[1]
+    finally:
+        layers.conv_arithmetic("bf16x3")
+    f1, d1 = flow(left[:1], left[1:2], iters=6)[1], stereo(left[:1], right[:1], iters=6)[1]
+    assert not torch.equal(f0, f1)                                   # the switch did change the arithmetic
+    assert _epe(f1, f0) < 1e-3 and (d1 - d0).abs().mean().item() < 1e-3
+    _, f_ref = raft_ref.raft_flow_forward(flow, left[:1], left[1:2], iters=6)
+    _, d_ref = raft_ref.raft_stereo_forward(stereo, left[:1], right[:1], iters=6)
+    assert _epe(f1, f_ref) < 1e-3 and (d1 - d_ref).abs().mean().item() < 1e-3
+    assert _epe(f0, f_ref) < 1e-3 and (d0 - d_ref).abs().mean().item() < 1e-3
+
+
 @pytest.mark.parametrize("N,C,H,W,K", [(1, 8, 5, 7, 64), (2, 16, 33, 21, 40), (2, 64, 60, 80, 126), (1, 24, 1, 1, 33),
                                        (2, 384, 30, 40, 256), (1, 8, 70, 3, 32)])
 @pytest.mark.parametrize("vertical", [False, True])

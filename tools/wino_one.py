@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A few launches of a Winograd kernel at one shape (for rocprofv3 --pmc passes).
 Usage: wino_one.py N C H W K [reps] [tile]   tile 2 / 4: the 3x3 kernels; 5: the 1x5 GRU gate kernel;
-32: the streaming 3x3 stride-2 kernel"""
+32: the streaming 3x3 stride-2 kernel; 1: the split-bf16 direct 3x3 kernel"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,6 +18,10 @@ elif tile == 32:
     Wg = ops.conv3x3s2_filter(torch.randn(K, C, 3, 3, device="cuda") * 0.05)
     for _ in range(reps):
         y = ops.conv3x3s2(x, Wg, K)
+elif tile == 1:
+    U = ops.conv3x3_split_filter(torch.randn(K, C, 3, 3, device="cuda") * 0.05)
+    for _ in range(reps):
+        y = ops.conv3x3_winograd(x, U, K)
 else:
     U = ops.winograd_filter(torch.randn(K, C, 3, 3, device="cuda") * 0.05, tile)
     for _ in range(reps):

@@ -1,0 +1,404 @@
+// 3x3 stride-1 convolution (padding 1), float32 in and out, with every float32 product formed
+// from bf16 pieces on the bf16 matrix cores:
+//
+//     x = xh + xl (+ 2^-16 x),  w = wh + wl (+ 2^-16 w),   xh = bf16(x), xl = bf16(x - xh)
+//     x * w  ~  xl*wh + xh*wl + xh*wh        (three v_mfma_f32_32x32x16_bf16, float32 accumulation)
+//
+// The term left out (xl*wl) and the rounding of the low parts are 2^-16 of a product, i.e. each
+// product keeps 16 significant bits (TF32, the tensor-core default of the reference's framework
+// for convolutions, keeps 10); on the networks' layers the largest error is 4-6e-6 of the largest
+// output, below the float32 Winograd F(4x4,3x3) kernel's 1e-5.  The float32 matrix instruction
+// runs at the vector rate (1/16 of the bf16 rate), so three bf16 instructions per product are
+// still five times its throughput, and the direct form needs no transforms.
+//
+// Implicit GEMM: out[k, pixel] = sum over (tap, c) of W[k, c, tap] * x[c, pixel + tap].
+//   workgroup = 4 waves: 64 (or 32) output channels x 16 rows x 32 columns of one image
+//   wave w    = rows 4w..4w+3: 2 x 4 accumulator tiles of 32 channels x 32 pixels (128 registers)
+//   input channels stream in chunks of 16 (one k-step): the 18 x 36 patch of a chunk is split into
+//   high and low parts while it is staged and lies in LDS as [part][k-half][row][column][8 channels]
+//   (a lane's B fragment of any tap is one 16-byte read, lanes on consecutive 16-byte slots);
+//   weights are pre-split and pre-arranged in operand order; a chunk's 36 KiB are copied to LDS as
+//   they are.  The multiply phase reads only LDS; two workgroups share a CU (78.5 KiB each) so that
+//   one stages while the other multiplies.
+#include "vo_common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CK = 16;                        // input channels per chunk (the k of one matrix instruction)
+constexpr int KB = 64;                        // output channels per workgroup
+constexpr int TH = 16, TW = 32;               // output tile of a workgroup in pixels
+constexpr int PR = TH + 2;                    // patch rows
+constexpr int PC = TW + 4;                    // patch columns [x0 - 2, x0 + 34): 8-byte aligned pairs
+constexpr int PLANE = PR * PC * 16;           // bytes of one (part, k-half) plane: 16 bytes per pixel
+constexpr int NT = 256;                       // threads per workgroup
+constexpr int UNITS = 2 * PR * (PC / 2);      // staging units: (k-half, row, column pair) = 648
+constexpr int ROUNDS = (UNITS + NT - 1) / NT; // 3
+constexpr int A_TAP = 2 * 2 * 64 * 16;        // bytes of weights per (chunk, tap): [part][m-tile][lane][16]
+constexpr int A_CHUNK = 9 * A_TAP;            // 36864
+constexpr int MAX_NORM_C = 256;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 p = __builtin_convertvector(v, bf16x2);          // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned, p);
+}
+
+// Weights (K,C,3,3) float32 -> high and low bf16 parts in the register order of the A operand:
+//   Ag[kb][chunk][tap][part][mt][lane][j]:  k = kb*64 + mt*32 + (lane & 31),  c = chunk*16 + 8*(lane >> 5) + j
+__global__ __launch_bounds__(256) void filter_split_kernel(const float* __restrict__ g, unsigned short* __restrict__ Ag,
+                                                           int K, int C, int Kpad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Kpad * C) return;
+    const int k = (int)(idx / C), c = (int)(idx % C);
+    const int kb = k >> 6, mt = (k >> 5) & 1, kl = k & 31, chunk = c >> 4, kg = (c >> 3) & 1, j = c & 7;
+    const int nchunks = C / CK;
+    for (int tap = 0; tap < 9; ++tap) {
+        const float w = k < K ? g[((int64_t)k * C + c) * 9 + tap] : 0.0f;
+        const unsigned hi = pack_bf16(w, 0.0f) & 0xffffu;
+        const float rest = w - __uint_as_float(hi << 16);
+        const unsigned lo = pack_bf16(rest, 0.0f) & 0xffffu;
+        const int64_t base = ((((int64_t)kb * nchunks + chunk) * 9 + tap) * 2) * 2;          // [part][mt]
+        const int lane = kg * 32 + kl;
+        Ag[((base + 0 * 2 + mt) * 64 + lane) * 8 + j] = (unsigned short)hi;
+        Ag[((base + 1 * 2 + mt) * 64 + lane) * 8 + j] = (unsigned short)lo;
+    }
+}
+
+struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; double* stats; };
+struct InputNorm { const double* stats; float eps; };
+
+// MT: 32-channel tiles per workgroup (2: 64 output channels; 1: a last block of at most 32).
+template <bool NORM_IN, int MT>
+__global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
+                                                               float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H,
+                                                               int W, int K, int blocks_x, int blocks_y, int kblocks,
+                                                               int kb_base) {
+    // patch | weights of the chunk | (NORM_IN) per-channel scale and shift.  The reduction buffer of the
+    // statistics epilogue re-uses the patch area after the last chunk.
+    __shared__ __align__(16) unsigned char lds[4 * PLANE + A_CHUNK + (NORM_IN ? MAX_NORM_C * 8 : 0)];
+    float2* nrm = reinterpret_cast<float2*>(lds + 4 * PLANE + A_CHUNK);
+    float* red = reinterpret_cast<float*>(lds);                              // [2][4 waves][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid;
+    {   // one contiguous range of the block list per XCD (workgroups are dealt round robin over 8)
+        const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+        bid = (int)(((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3));
+    }
+    const int kb = kb_base + bid % kblocks; bid /= kblocks;
+    const int bx = bid % blocks_x; bid /= blocks_x;
+    const int by = bid % blocks_y;
+    const int n = bid / blocks_y;
+    const int nchunks = C / CK;
+    const int y0 = by * TH, x0 = bx * TW;
+    const int HW4 = H * W * 4;
+
+    const float* xn = x + (int64_t)n * C * H * W;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, C * HW4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(Ag) + (int64_t)kb * nchunks * (A_CHUNK / 2), 0, nchunks * A_CHUNK, 0x00020000);
+
+    // staging units of this thread: (k-half, patch row, column pair); a unit outside the image carries an
+    // offset past the extent, which the range check of a buffer load turns into zeros (the padding)
+    int u_off[ROUNDS], u_lds[ROUNDS];
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i) {
+        const int u = tid + i * NT;
+        const int kg = u / (PR * (PC / 2)), rem = u - kg * (PR * (PC / 2)), row = rem / (PC / 2), pr = rem - row * (PC / 2);
+        const int gy = y0 - 1 + row, gx = x0 - 2 + 2 * pr;
+        const bool ok = u < UNITS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        u_off[i] = ok ? ((kg * 8 * H + gy) * W + gx) * 4 : (int)0x80000000;
+        u_lds[i] = kg * PLANE + (row * PC + 2 * pr) * 16;                    // + part * 2 * PLANE
+    }
+    if (NORM_IN) {
+        const double hw = (double)H * (double)W;
+        for (int c = tid; c < C; c += NT) {
+            const double* st = in.stats + ((int64_t)n * C + c) * 2;
+            const double mean = st[0] / hw;
+            double var = st[1] / hw - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float r = (float)(1.0 / sqrt(var + (double)in.eps));
+            nrm[c] = make_float2(r, -(float)mean * r);
+        }
+    }
+
+    u32x2 rv[ROUNDS][8];
+    auto load_raw = [&](int chunk) {
+        chunk = chunk < nchunks ? chunk : nchunks - 1;                       // past the end: reloaded, never used
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            if (i * NT + NT > UNITS && tid + i * NT >= UNITS) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, u_off[i], (chunk * CK + j) * HW4, 0);
+        }
+    };
+    auto store_raw = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            if (i * NT + NT > UNITS && tid + i * NT >= UNITS) continue;
+            float v[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j][0] = __uint_as_float(rv[i][j][0]);
+                v[j][1] = __uint_as_float(rv[i][j][1]);
+            }
+            if (NORM_IN) {                                                   // the padding pads the NORMALISED tensor: it stays zero
+                const int kg = (tid + i * NT) / (PR * (PC / 2));
+                const bool ok = u_off[i] >= 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 ss = nrm[chunk * CK + kg * 8 + j];
+                    v[j][0] = ok ? fmaxf(fmaf(v[j][0], ss.x, ss.y), 0.0f) : 0.0f;
+                    v[j][1] = ok ? fmaxf(fmaf(v[j][1], ss.x, ss.y), 0.0f) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                u32x4 hi, lo;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float a = v[2 * jj][px], b = v[2 * jj + 1][px];
+                    const unsigned h = pack_bf16(a, b);
+                    hi[jj] = h;
+                    lo[jj] = pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+                }
+                *reinterpret_cast<u32x4*>(lds + u_lds[i] + px * 16) = hi;
+                *reinterpret_cast<u32x4*>(lds + 2 * PLANE + u_lds[i] + px * 16) = lo;
+            }
+        }
+    };
+
+    f32x16 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
+
+    // A fragment of (tap, part, mt): weights area + ((tap*2 + part)*2 + mt) KiB + 16*lane
+    // B fragment of (tap r, s), pixel tile nt: patch row 4*wave + nt + r, patch column (lane & 31) + s + 1
+    const unsigned char* a_lds = lds + 4 * PLANE + lane * 16;
+    const unsigned char* b_lds = lds + (lane >> 5) * PLANE + ((4 * wave) * PC + (lane & 31) + 1) * 16;
+    auto read_a = [&](int tap, int part, int mt) {
+        return *reinterpret_cast<const bf16x8*>(a_lds + ((tap * 2 + part) * 2 + mt) * 1024);
+    };
+    auto read_b = [&](int tap, int nt, int part) {
+        return *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PLANE + ((nt + tap / 3) * PC + tap % 3) * 16);
+    };
+    constexpr int A_PIECES = A_CHUNK / 16 / NT;                              // 9 sixteen-byte pieces per thread and chunk
+
+    // a chunk's weights are a linear copy (they are stored in operand order); they are requested at the
+    // end of the previous chunk's multiply phase, so their latency passes under the barrier and the
+    // conversion of the patch
+    u32x4 aw[A_PIECES];
+    auto load_aw = [&](int chunk) {
+        chunk = chunk < nchunks ? chunk : nchunks - 1;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+            aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ars, (tid + i * NT) * 16, chunk * A_CHUNK, 0);
+    };
+    load_raw(0);
+    load_aw(0);
+    if (NORM_IN) __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        store_raw(chunk);
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) *reinterpret_cast<u32x4*>(lds + 4 * PLANE + (tid + i * NT) * 16) = aw[i];
+        __syncthreads();
+        load_raw(chunk + 1);                                                 // in flight during the whole multiply phase
+
+        // 36 steps of (tap, pixel tile): 3*MT matrix instructions each, operands double-buffered in
+        // registers: a step issues the reads of the next one (and a quarter of the next tap's weights)
+        bf16x8 fa[2][2][MT], fb[2][2];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[0][part][mt] = read_a(0, part, mt);
+            fb[0][part] = read_b(0, 0, part);
+        }
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            const int tap = st >> 2, nt = st & 3, ca = tap & 1, cb = st & 1;
+            if (st + 1 < 36) {
+                fb[cb ^ 1][0] = read_b((st + 1) >> 2, (st + 1) & 3, 0);
+                fb[cb ^ 1][1] = read_b((st + 1) >> 2, (st + 1) & 3, 1);
+            }
+            if (tap + 1 < 9 && nt < 2 * MT) fa[ca ^ 1][nt / MT][nt % MT] = read_a(tap + 1, nt / MT, nt % MT);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                // the small terms first, so that they are not rounded away against the large one
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][1][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][1], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+            }
+            // the step's reads first (they feed the NEXT step), then its matrix instructions
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_aw(chunk + 1);
+        __syncthreads();                                                     // everyone has read the patch and the weights
+    }
+
+    // Epilogue.  C/D layout of the 32x32 tile: pixel = lane & 31, channel row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
+    float* yn = y + (int64_t)n * ep.y_batch_stride;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yn, 0, K * HW4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ep.skip ? ep.skip + (int64_t)n * K * H * W : x), 0, ep.skip ? K * HW4 : 0, 0x00020000);
+    const int col = x0 + (lane & 31), lh = lane >> 5;
+    const int row0 = y0 + 4 * wave;
+
+    if (ep.stats) {
+        // plane sums of the raw output: per lane over its four rows, then over the 32 pixel lanes by a
+        // halving exchange (each step hands half of the lane's channel rows to the partner lane and adds
+        // the partner's half to its own), then over the four waves through LDS: one pair of float64
+        // atomics per channel and workgroup
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float s1[16], s2[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s1[e] = 0.0f; s2[e] = 0.0f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bool ok = row0 + nt < H && col < W;
+                    const float v = ok ? acc[mt][nt][e] : 0.0f;
+                    s1[e] += v; s2[e] = fmaf(v, v, s2[e]);
+                }
+            }
+            // 16 values on 32 lanes -> lane l (of 32) ends with the total of value (l & 15)
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                const int m = 16 >> step;                                    // lane mask 16, 8, 4, 2; values kept: 8, 4, 2, 1
+                const int keep = 8 >> step;
+                const bool upper = (lane & m) != 0;
+#pragma unroll
+                for (int i = 0; i < keep; ++i) {
+                    const float mine1 = upper ? s1[i + keep] : s1[i], send1 = upper ? s1[i] : s1[i + keep];
+                    const float mine2 = upper ? s2[i + keep] : s2[i], send2 = upper ? s2[i] : s2[i + keep];
+                    s1[i] = mine1 + __shfl_xor(send1, m, VO_WAVE);
+                    s2[i] = mine2 + __shfl_xor(send2, m, VO_WAVE);
+                }
+            }
+            s1[0] += __shfl_xor(s1[0], 1, VO_WAVE);
+            s2[0] += __shfl_xor(s2[0], 1, VO_WAVE);
+            // lane l now holds value index v(l) = bits (l>>4 &1)*8 + (l>>3 &1)*4 + (l>>2 &1)*2 + (l>>1 &1), both lanes of a pair
+            if ((lane & 1) == 0) {
+                const int l5 = lane & 31;
+                const int e = ((l5 >> 4) & 1) * 8 + ((l5 >> 3) & 1) * 4 + ((l5 >> 2) & 1) * 2 + ((l5 >> 1) & 1);
+                const int krow = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                red[(0 * 4 + wave) * 64 + krow] = s1[0];
+                red[(1 * 4 + wave) * 64 + krow] = s2[0];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * 32 * MT) {
+            const int which = tid / (32 * MT), krow = tid - which * (32 * MT);
+            const float* rp = red + which * 4 * 64 + krow;
+            const double tot = (double)rp[0] + (double)rp[64] + (double)rp[128] + (double)rp[192];
+            const int k = kb * KB + krow;
+            if (k < K) atomicAdd(ep.stats + ((int64_t)n * K + k) * 2 + which, tot);
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float sc[16], sh[16];
+        int koff[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = kb * KB + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const bool kok = k < K;
+            sc[e] = 1.0f; sh[e] = 0.0f;
+            if (ep.shift && kok) { sc[e] = ep.scale ? ep.scale[k] : 1.0f; sh[e] = ep.shift[k]; }
+            koff[e] = kok ? k * HW4 : (int)0x80000000;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int row = row0 + nt;
+            const bool pok = row < H && col < W;
+            const int poff = (row * W + col) * 4;
+            float sk[16];
+            if (ep.skip) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    sk[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srs, pok ? koff[e] + poff : (int)0x80000000, 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[mt][nt][e];
+                if (ep.shift) v = fmaf(v, sc[e], sh[e]);
+                if (ep.relu) v = fmaxf(v, 0.0f);
+                if (ep.skip) v = fmaxf(v + sk[e], 0.0f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (pok && koff[e] >= 0) ? koff[e] + poff : (int)0x80000000, 0, 0);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vo_conv3x3_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream) {
+    VO_REQUIRE(weight && arranged, "vo_conv3x3_bf16x3_filter: null pointer");
+    VO_REQUIRE(K > 0 && C > 0, "vo_conv3x3_bf16x3_filter: bad sizes K=%d C=%d", K, C);
+    if (C % CK != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3_filter: C=%d is not a multiple of %d", C, CK);
+    const int Kpad = (K + KB - 1) / KB * KB;
+    const int64_t n = (int64_t)Kpad * C;
+    filter_split_kernel<<<dim3((unsigned)vo_ceil_div(n, 256)), dim3(256), 0, vo_stream(stream)>>>(
+        weight, static_cast<unsigned short*>(arranged), K, C, Kpad);
+    VO_CHECK_LAUNCH("vo_conv3x3_bf16x3_filter");
+    return VO_OK;
+}
+
+extern "C" int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
+                                 const float* scale, const float* shift, int relu, const float* skip, double* stats,
+                                 const double* in_stats, float in_eps, int N, int C, int H, int W, int K, void* stream) {
+    VO_REQUIRE(x && arranged && y, "vo_conv3x3_bf16x3: null pointer");
+    VO_REQUIRE(!scale || shift, "vo_conv3x3_bf16x3: scale without shift");
+    VO_REQUIRE(!stats || (!shift && !relu && !skip), "vo_conv3x3_bf16x3: statistics are of the raw output, no epilogue with them");
+    VO_REQUIRE(skip != y, "vo_conv3x3_bf16x3: skip must not alias the output");
+    VO_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && K > 0, "vo_conv3x3_bf16x3: bad sizes");
+    if (y_batch_stride == 0) y_batch_stride = (int64_t)K * H * W;
+    VO_REQUIRE(y_batch_stride >= (int64_t)K * H * W, "vo_conv3x3_bf16x3: y_batch_stride smaller than one item");
+    if (C % CK != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: C=%d is not a multiple of %d", C, CK);
+    if (W % 2 != 0 || (reinterpret_cast<uintptr_t>(x) & 7) != 0)
+        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: needs an even width and an 8-byte aligned input (W=%d)", W);
+    if ((int64_t)C * H * W * 4 >= 0x7fffffffLL || (int64_t)K * H * W * 4 >= 0x7fffffffLL)
+        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: one image of the input or output exceeds 2 GiB");
+    if (in_stats && C > MAX_NORM_C)
+        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: normalise-on-load supports at most %d input channels", MAX_NORM_C);
+    const int bx = (W + TW - 1) / TW, by = (H + TH - 1) / TH;
+    const int64_t blocks = (int64_t)bx * by * N;
+    const int kblocks = (K + KB - 1) / KB;
+    if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: grid too large");
+    const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats};
+    const InputNorm nrm{in_stats, in_eps};
+    const unsigned short* ag = static_cast<const unsigned short*>(arranged);
+    // a last block with at most 32 channels goes out as a launch of its own with one channel tile
+    const int rem = K % KB;
+    const int full = (rem >= 1 && rem <= 32) ? kblocks - 1 : kblocks;
+    hipStream_t st = vo_stream(stream);
+    if (full > 0) {
+        const dim3 grid((unsigned)(blocks * full));
+        if (in_stats) conv3x3_bf16x3_kernel<true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, full, 0);
+        else conv3x3_bf16x3_kernel<false, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, full, 0);
+    }
+    if (full < kblocks) {
+        const dim3 grid((unsigned)blocks);
+        if (in_stats) conv3x3_bf16x3_kernel<true, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, 1, full);
+        else conv3x3_bf16x3_kernel<false, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, 1, full);
+    }
+    VO_CHECK_LAUNCH("vo_conv3x3_bf16x3");
+    return VO_OK;
+}

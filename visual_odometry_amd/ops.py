@@ -231,6 +231,20 @@ def winograd_filter(weight: torch.Tensor, tile: int = 2) -> torch.Tensor:
     return out
 
 
+def conv3x3_split_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,3,3) float32 weight -> the bf16 high/low parts in operand order that conv3x3_winograd
+    hands to the split-bf16 direct kernel (a float32 tensor used as raw storage, ceil(K/64)*64*C*9
+    elements).  C must be a multiple of 16."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError("weight must be (K,C,3,3)")
+    K, C = weight.shape[:2]
+    if C % 16:
+        raise ValueError("the split-bf16 path needs a multiple of 16 input channels")
+    out = torch.empty(((K + 63) // 64 * 64 * C * 9,), device=weight.device, dtype=torch.float32)
+    _call("vo_conv3x3_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    return out
+
+
 def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: torch.Tensor | None = None,
                      shift: torch.Tensor | None = None, relu: bool = False,
                      skip: torch.Tensor | None = None, out: torch.Tensor | None = None,
@@ -250,6 +264,11 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
         name, tile, positions = "vo_conv3x3_winograd", 2, 16
     elif transformed.numel() == per_position * 36:
         name, tile, positions = "vo_conv3x3_winograd4", 4, 36
+    elif transformed.numel() == per_position * 9:
+        # split-bf16 direct kernel: three bf16 matrix instructions per product, 9 taps
+        name, tile, positions = "vo_conv3x3_bf16x3", 1, 27
+        if W % 2:
+            raise ValueError("the split-bf16 kernel needs an even width")
     else:
         raise ValueError("transformed filter does not match (K, C)")
     for t, tname in ((scale, "scale"), (shift, "shift")):
@@ -274,7 +293,8 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
           _opt(skip, "skip", torch.float32), _opt(stats, "stats", torch.float64),
           _opt(in_stats, "in_stats", torch.float64), float(in_eps), N, C, H, W, K, _stream(),
           nbytes=4 * (x.numel() + out.numel() * (1 + (skip is not None))),
-          flops=2 * positions * C * K * N * ((H + tile - 1) // tile) * ((W + tile - 1) // tile))   # transformed-domain multiply-adds
+          flops=2 * positions * C * K * N * ((H + tile - 1) // tile) * ((W + tile - 1) // tile))   # multiply-adds the kernel issues
+                                                                                                  # (Winograd domain / three bf16 terms)
     return out
 
 

@@ -109,6 +109,20 @@ def conv_pixel_major(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
 
 _WINOGRAD = True            # float32 3x3 stride-1 convolutions on the hand-written Winograd/MFMA kernels
 _WINOGRAD_TILE = 0          # 0: pick F(2x2,3x3) or F(4x4,3x3) per layer shape; 2 or 4: force one
+_SPLIT_BF16 = True          # 3x3 layers on the split-bf16 direct kernel where it applies (see conv_arithmetic)
+
+
+def conv_arithmetic(kind: str) -> None:
+    """How the float32 3x3 convolutions form their products:
+      "bf16x3" (default)  every float32 product from bf16 pieces, x*w ~ xl*wh + xh*wl + xh*wh, on the
+                          bf16 matrix cores with float32 accumulation (16 significant bits per product,
+                          largest error 4-6e-6 of a layer's largest output);
+      "f32"               float32 matrix instructions only (the Winograd kernels; the F(4x4,3x3) form's
+                          rounding error is 1e-5 of the largest output)."""
+    global _SPLIT_BF16
+    if kind not in ("bf16x3", "f32"):
+        raise ValueError("conv_arithmetic must be 'bf16x3' or 'f32'")
+    _SPLIT_BF16 = kind == "bf16x3"
 
 
 def winograd_enabled(on: bool) -> None:
@@ -125,15 +139,20 @@ def winograd_tile(tile: int) -> None:
     _WINOGRAD_TILE = tile
 
 
-def _winograd_tile_for(H: int, W: int) -> int:
-    """F(4x4,3x3) does a pixel in about 1/1.55 of F(2x2,3x3)'s time but works on 16x32- or
-    32x16-pixel blocks (whichever covers the map with less padding) instead of 16x16: take it
-    unless the padding of small maps eats the gain."""
+def _winograd_tile_for(H: int, W: int, C: int = 0) -> int:
+    """Which 3x3 kernel: 1 = the split-bf16 direct kernel, 4 / 2 = Winograd F(4x4,3x3) / F(2x2,3x3).
+    F(4x4,3x3) does a pixel in about 1/1.55 of F(2x2,3x3)'s time but works on 16x32- or 32x16-pixel
+    blocks (whichever covers the map with less padding) instead of 16x16: take it unless the padding
+    of small maps eats the gain.  The split-bf16 kernel does a pixel in about 1/1.3 of F(4x4,3x3)'s
+    time on 16x32-pixel blocks; it needs input channels in multiples of 16 and an even width."""
     if _WINOGRAD_TILE:
         return _WINOGRAD_TILE
     up = lambda v, m: (v + m - 1) // m * m
     covered4 = min(up(H, 16) * up(W, 32), up(H, 32) * up(W, 16))
-    return 4 if covered4 < 1.55 * up(H, 16) * up(W, 16) else 2
+    best = (4, covered4) if covered4 < 1.55 * up(H, 16) * up(W, 16) else (2, 1.55 * up(H, 16) * up(W, 16))
+    if _SPLIT_BF16 and C % 16 == 0 and C > 0 and W % 2 == 0 and up(H, 16) * up(W, 32) < 1.3 * best[1]:
+        return 1
+    return best[0]
 
 
 def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
@@ -147,7 +166,7 @@ def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
         return None
     # the transformed filters ride on the weight tensor object itself (an address-keyed
     # table would hand a new model the filters of a freed one), one per kernel variant
-    tile = _winograd_tile_for(x.shape[2], x.shape[3])
+    tile = _winograd_tile_for(x.shape[2], x.shape[3], x.shape[1])
     key = (weight._version, weight.data_ptr())
     table = getattr(weight, "_vo_winograd", None)
     if table is None or table[0] != key:
@@ -155,7 +174,8 @@ def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
         weight._vo_winograd = table
     U = table[1].get(tile)
     if U is None:
-        U = table[1][tile] = ops.winograd_filter(weight.contiguous(), tile)
+        U = table[1][tile] = (ops.conv3x3_split_filter(weight.contiguous()) if tile == 1
+                              else ops.winograd_filter(weight.contiguous(), tile))
     return U
 
 
@@ -407,7 +427,7 @@ class ResidualBlock(nn.Module):
             return None
         c1, c2 = self.conv1, self.conv2
         U1 = _winograd_filter_for(x, c1.weight, c1.stride, c1.padding, c1.dilation, c1.groups)
-        if U1 is None or c2.in_channels > 512 or x.shape[0] * max(c1.out_channels, c2.out_channels) > 65535:
+        if U1 is None or c2.in_channels > 256 or x.shape[0] * max(c1.out_channels, c2.out_channels) > 65535:
             return None
         st1 = torch.zeros((x.shape[0], c1.out_channels, 2), device=x.device, dtype=torch.float64)
         y1 = ops.conv3x3_winograd(x, U1, c1.out_channels, stats=st1)
