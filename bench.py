@@ -38,6 +38,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak
+# kernels whose float32 products are three bf16 matrix-core terms: their recorded FLOPs are the bf16
+# multiply-adds they issue (three per product), priced against the bf16 peak
+SPLIT_BF16_KERNELS = ("vo_conv3x3_bf16x3", "vo_conv5_bf16x3", "vo_conv3x3s2_bf16x3")
 
 
 def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256):
@@ -67,7 +71,8 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
 
 PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_corr_pyramid_2d": "pyr2d",
             "vo_corr_pyramid_1d": "pyr1d", "vo_corr_lookup_2d": "lookup2d", "vo_corr_lookup_1d": "lookup1d",
-            "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4", "vo_conv5_winograd": "winograd1d"}
+            "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4", "vo_conv5_winograd": "winograd1d",
+            "vo_conv3x3_bf16x3": "conv3x3_bf16x3"}
 
 
 def pmc_traffic(kernel: str, B: int, H: int, W: int):
@@ -253,6 +258,9 @@ def main():
     ap.add_argument("--no-config-legs", action="store_true",
                     help="skip the secondary measurements of the reference's default (full) argument set")
     ap.add_argument("--pose", choices=["svd", "ransac"], default="svd")
+    ap.add_argument("--conv-arithmetic", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="how the heavy float32 convolutions multiply: three bf16 matrix-core terms per product "
+                         "(default) or float32 matrix instructions only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,6 +280,8 @@ def main():
 
     H, W, B = args.height, args.width, args.batch
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    from visual_odometry_amd.raft import layers as raft_layers
+    raft_layers.conv_arithmetic(args.conv_arithmetic)
     def make_vo(mixed, stereo=args.stereo, iters=args.iters, pose=args.pose):
         cfg = VOConfig(iters=iters,
                        stereo=RAFTStereoConfig.realtime() if stereo == "realtime" else RAFTStereoConfig(),
@@ -361,9 +371,15 @@ def main():
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     d = kernels[dom]
     if "TFLOPs" in d:
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": d["TFLOPs"], "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": d["TFLOPs"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+        peak = BF16_MFMA_PEAK_TFLOPS if dom in SPLIT_BF16_KERNELS else F32_MFMA_PEAK_TFLOPS
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": d["TFLOPs"], "peak": peak,
+                    "unit": "TFLOP/s", "frac": d["TFLOPs"] / peak, "traffic": None,
                     "avg_launch_us": d["avg_us"], "hbm_GBps": d.get("GBps")}
+        if dom in SPLIT_BF16_KERNELS:
+            roofline["float32_equivalent_TFLOPs"] = d["TFLOPs"] / 3.0
+            roofline["note"] = ("mean over all launches of one step; achieved counts the bf16 multiply-adds the kernel issues "
+                                "(three per float32 product: xl*wh + xh*wl + xh*wh), peak is the dense bf16 matrix rate; "
+                                "float32_equivalent_TFLOPs = the direct convolution's own FLOPs per second (f32 MFMA peak: 157.3)")
     else:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
@@ -389,7 +405,12 @@ def main():
             "metric": "VO frame-pairs/sec at 640x480 (flow+stereo+pose)", "value": value, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 activations, f32 weights/correlation/geometry" if args.mixed_precision else "f32",
+            "vs_baseline": None,
+            "dtype": ("f16 activations, f32 weights/correlation/geometry" if args.mixed_precision else
+                      ("f32" if args.conv_arithmetic == "f32" else
+                       "f32 (tensors, accumulation and every other operator in float32; the products of the 3x3, 1x5/5x1 and "
+                       "stride-2 3x3 convolutions are assembled from three bf16 matrix-core terms, 16 significant bits each, "
+                       "measured error below the float32 Winograd kernels' -- see f32_mfma_only for those)")),
             "data": "synthetic",
             "config": {"workload": f"RAFT-Flow + RAFT-Stereo({args.stereo} args) {W}x{H}, {args.iters} iters, "
                                    f"{n_kp} grid keypoints, {'Kabsch' if args.pose == 'svd' else 'RANSAC'} pose; "
@@ -424,6 +445,16 @@ def main():
                                   "note": "frames from pinned host memory, chunk k+1 uploaded on a second stream "
                                           "while chunk k computes; includes the first chunk's halo stereo frame"}
             del lh, rh
+        if world == 1 and not args.mixed_precision and args.conv_arithmetic == "bf16x3" and not args.no_config_legs:
+            # the same step with float32 matrix instructions only (the Winograd kernels)
+            raft_layers.conv_arithmetic("f32")
+            try:
+                dt32 = timed_steps(vo, left, right, cached, max(1, min(args.steps, 3)), 1)
+            finally:
+                raft_layers.conv_arithmetic("bf16x3")
+            out["f32_mfma_only"] = {"value": B / dt32, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt32, "dtype": "f32",
+                                    "note": "every convolution on float32 matrix instructions (v_mfma_f32_32x32x2_f32), "
+                                            "which run at the vector rate, 1/16 of the bf16 matrix rate"}
         if world == 1 and not args.mixed_precision and not args.no_mixed_precision_leg:
             out["mixed_precision"] = mixed_precision_leg(vo, make_vo(True), left, right, cached, args.steps)
         if world == 1 and not args.no_cpu_baseline:

@@ -161,6 +161,23 @@ int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_
                       double* stats, const double* in_stats, float in_eps,
                       int N, int C, int H, int W, int K, void* stream);
 
+/* The same split-bf16 arithmetic for the two other heavy layer types (one kernel template):
+ *   vo_conv5_bf16x3      1x5 (padding (0,2)) / 5x1 (padding (2,0)) stride-1 convolution, the gate
+ *                        convolutions of RAFT's separable GRU (vertical = 0 / 1); weights from
+ *                        vo_conv5_bf16x3_filter ((K,C,5) float32 -> ceil(K/64)*64 * C * 5 * 4 bytes);
+ *                        optional epilogue v*scale[k] + shift[k], ReLU; y may be a channel slice.
+ *   vo_conv3x3s2_bf16x3  3x3 stride-2 padding-1 convolution, the encoders' downsampling layers: x (N,C,H,W)
+ *                        -> y (N,K,(H-1)/2+1,(W-1)/2+1); weights from vo_conv3x3_bf16x3_filter; optional
+ *                        epilogue as above, or stats (N,K,2) float64 as vo_conv3x3_winograd's.
+ * C a multiple of 16, W even, x 8-byte aligned. */
+int vo_conv5_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv5_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
+                    const float* scale, const float* shift, int relu,
+                    int N, int C, int H, int W, int K, int vertical, void* stream);
+int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y,
+                        const float* scale, const float* shift, int relu, double* stats,
+                        int N, int C, int H, int W, int K, void* stream);
+
 /* 1x5 (padding (0,2)) and 5x1 (padding (2,0)) stride-1 float32 convolutions, NCHW, no bias, as
  * one-dimensional Winograd F(4,5) on the matrix cores: the gate convolutions of the separable
  * GRU in RAFT's update block (model built at flow/flow_map_RAFT.py:42).

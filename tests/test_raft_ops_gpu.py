@@ -708,6 +708,64 @@ def test_split_bf16_conv3x3_epilogue_statistics_and_slices(vo):
     assert (a - bb).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
 
 
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 16, 5, 8, 64), (2, 32, 33, 22, 40), (2, 64, 60, 80, 126), (1, 16, 1, 2, 33),
+                                       (2, 384, 30, 40, 256), (1, 48, 70, 4, 32), (3, 384, 60, 80, 128)])
+@pytest.mark.parametrize("vertical", [False, True])
+def test_split_bf16_conv5_matches_direct_convolution(vo, N, C, H, W, K, vertical):
+    """1x5 / 5x1 GRU gate convolutions on the split-bf16 direct kernel against the float64 direct
+    convolution (ragged sizes, partial channel blocks, run-to-run identical), the fused bias + ReLU and
+    a channel-slice output."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=110).to(DEV)
+    shape = (K, C, 5, 1) if vertical else (K, C, 1, 5)
+    w = (_rand(*shape, seed=111) / (5 * C) ** 0.5).to(DEV)
+    U = ops.conv5_split_filter(w)
+    got = ops.conv5_split(x, U, K, vertical)
+    want = Fn.conv2d(x.double(), w.double(), None, 1, (2, 0) if vertical else (0, 2))
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max().item() < SPLIT_TOL * max(1.0, want.abs().max().item())
+    assert torch.equal(got, ops.conv5_split(x, U, K, vertical))
+    bias = _rand(K, seed=112).to(DEV)
+    wide = torch.full((N, 3 + K + 2, H, W), 1.75, device=DEV)
+    ops.conv5_split(x, U, K, vertical, None, bias, True, out=wide[:, 3:3 + K])
+    ref = torch.relu(want.float() + bias[None, :, None, None])
+    assert (wide[:, 3:3 + K] - ref).abs().max().item() < SPLIT_TOL * max(1.0, want.abs().max().item())
+    assert torch.all(wide[:, :3] == 1.75) and torch.all(wide[:, 3 + K:] == 1.75)
+    with pytest.raises(ValueError):
+        ops.conv5_split_filter(_rand(8, 24, 1, 5, seed=1).to(DEV))
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 16, 5, 8, 64), (2, 16, 33, 70, 40), (2, 64, 9, 132, 100), (1, 16, 1, 2, 3),
+                                       (2, 64, 60, 80, 96), (1, 96, 61, 62, 128), (3, 128, 120, 160, 128)])
+def test_split_bf16_conv3x3s2_matches_the_stock_convolution(vo, N, C, H, W, K):
+    """3x3 stride-2 convolution on the split-bf16 direct kernel (even and odd columns of the staged patch
+    stored apart) against the float64 stock convolution: odd and even heights, ragged widths, the fused
+    scale / shift / ReLU, and the plane statistics for a following instance norm."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=120).to(DEV)
+    w = (_rand(K, C, 3, 3, seed=121) / (3 * C ** 0.5)).to(DEV)
+    U = ops.conv3x3_split_filter(w)
+    got = ops.conv3x3s2_split(x, U, K)
+    want = Fn.conv2d(x.double(), w.double(), None, 2, 1)
+    assert got.shape == want.shape
+    tol = SPLIT_TOL * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() < tol
+    assert torch.equal(got, ops.conv3x3s2_split(x, U, K))
+    scale, shift = _rand(K, seed=122).to(DEV), _rand(K, seed=123).to(DEV)
+    got = ops.conv3x3s2_split(x, U, K, scale, shift, True)
+    ref = torch.relu(want.float() * scale[None, :, None, None] + shift[None, :, None, None])
+    assert (got - ref).abs().max().item() < 2 * tol
+    stats = torch.zeros((N, K, 2), device=DEV, dtype=torch.float64)
+    raw = ops.conv3x3s2_split(x, U, K, stats=stats)
+    want_stats = torch.stack([want.sum((2, 3)), (want * want).sum((2, 3))], dim=2)
+    assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
+    if want.shape[2] * want.shape[3] > 1:                       # torch refuses to normalise a one-pixel plane
+        got = ops.instance_norm_apply_(raw, stats, 1e-5, True)
+        assert (got - torch.relu(Fn.instance_norm(want.float(), eps=1e-5))).abs().max().item() < 5e-5
+
+
 def test_networks_agree_across_conv_arithmetic(vo):
     """Flow and disparity at 480x640 (every 3x3 layer large enough for the split-bf16 kernel) with the
     float32-matrix-instruction kernels only against the default split-bf16 products, and each against

@@ -41,3 +41,25 @@ for (N, C, H, W, K) in shapes:
         tst = timeit(lambda: ops.conv3x3_winograd(x, Us, K, stats=st))
         line += f" | +bias,relu,skip {tb:7.3f} ms err {eb:.1e} | stats {tst:7.3f} ms err {e_st:.1e}"
     print(line, flush=True)
+
+print("1x5 / 5x1 GRU gate convolutions and 3x3 stride-2 layers: float32-instruction kernel vs split-bf16")
+for (N, C, H, W, K) in [(64, 384, 60, 80, 256), (64, 384, 60, 80, 128)]:
+    for vertical in (False, True):
+        x = torch.randn(N, C, H, W, device="cuda")
+        w = torch.randn(*((K, C, 5, 1) if vertical else (K, C, 1, 5)), device="cuda") / (5 * C) ** 0.5
+        U1, Us = ops.winograd1d_filter(w), ops.conv5_split_filter(w)
+        want = F.conv2d(x.double(), w.double(), None, 1, (2, 0) if vertical else (0, 2)); scale = want.abs().max().item()
+        e1 = (ops.conv5_winograd(x, U1, K, vertical).double() - want).abs().max().item() / scale
+        es = (ops.conv5_split(x, Us, K, vertical).double() - want).abs().max().item() / scale
+        t1, ts = timeit(lambda: ops.conv5_winograd(x, U1, K, vertical)), timeit(lambda: ops.conv5_split(x, Us, K, vertical))
+        gf = 2 * N * K * H * W * C * 5 / 1e9
+        print(f"N{N:3d} {C:3d}->{K:3d} @{H}x{W} {'5x1' if vertical else '1x5'}: err wino {e1:.1e} split {es:.1e} | wino {t1:7.3f} ms ({gf/t1:6.1f})  split {ts:7.3f} ms ({gf/ts:6.1f})  x{t1/ts:.2f}", flush=True)
+for (N, C, H, W, K) in [(64, 64, 480, 640, 96), (64, 96, 240, 320, 128), (64, 128, 120, 160, 128), (64, 64, 240, 320, 96)]:
+    x = torch.randn(N, C, H, W, device="cuda"); w = torch.randn(K, C, 3, 3, device="cuda") / (3 * C ** 0.5)
+    Wg, Us = ops.conv3x3s2_filter(w), ops.conv3x3_split_filter(w)
+    want = F.conv2d(x[:2].double(), w.double(), None, 2, 1); scale = want.abs().max().item()
+    e1 = (ops.conv3x3s2(x[:2].contiguous(), Wg, K).double() - want).abs().max().item() / scale
+    es = (ops.conv3x3s2_split(x[:2].contiguous(), Us, K).double() - want).abs().max().item() / scale
+    t1, ts = timeit(lambda: ops.conv3x3s2(x, Wg, K)), timeit(lambda: ops.conv3x3s2_split(x, Us, K))
+    gf = 2 * N * K * (H // 2) * (W // 2) * C * 9 / 1e9
+    print(f"N{N:3d} {C:3d}->{K:3d} @{H}x{W} s2: err f32 {e1:.1e} split {es:.1e} | f32 {t1:7.3f} ms ({gf/t1:6.1f})  split {ts:7.3f} ms ({gf/ts:6.1f})  x{t1/ts:.2f}", flush=True)

@@ -33,6 +33,9 @@ SIGNATURES = {
     "vo_conv3x3_winograd4": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     "vo_conv3x3_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv3x3_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    "vo_conv5_bf16x3_filter": [_P, _P, _I, _I, _P],
+    "vo_conv5_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv3x3s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_winograd1d_filter": [_P, _P, _I, _I, _P],
     "vo_conv5_winograd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_filter": [_P, _P, _I, _I, _P],

@@ -1,5 +1,5 @@
-// 3x3 stride-1 convolution (padding 1), float32 in and out, with every float32 product formed
-// from bf16 pieces on the bf16 matrix cores:
+// Float32 convolutions (NCHW in and out) with every float32 product formed from bf16 pieces on the
+// bf16 matrix cores:
 //
 //     x = xh + xl (+ 2^-16 x),  w = wh + wl (+ 2^-16 w),   xh = bf16(x), xl = bf16(x - xh)
 //     x * w  ~  xl*wh + xh*wl + xh*wh        (three v_mfma_f32_32x32x16_bf16, float32 accumulation)
@@ -11,15 +11,19 @@
 // runs at the vector rate (1/16 of the bf16 rate), so three bf16 instructions per product are
 // still five times its throughput, and the direct form needs no transforms.
 //
-// Implicit GEMM: out[k, pixel] = sum over (tap, c) of W[k, c, tap] * x[c, pixel + tap].
-//   workgroup = 4 waves: 64 (or 32) output channels x 16 rows x 32 columns of one image
-//   wave w    = rows 4w..4w+3: 2 x 4 accumulator tiles of 32 channels x 32 pixels (128 registers)
-//   input channels stream in chunks of 16 (one k-step): the 18 x 36 patch of a chunk is split into
-//   high and low parts while it is staged and lies in LDS as [part][k-half][row][column][8 channels]
-//   (a lane's B fragment of any tap is one 16-byte read, lanes on consecutive 16-byte slots);
-//   weights are pre-split and pre-arranged in operand order; a chunk's 36 KiB are copied to LDS as
-//   they are.  The multiply phase reads only LDS; two workgroups share a CU (78.5 KiB each) so that
-//   one stages while the other multiplies.
+// One kernel template, three layer types: 3x3 stride 1 (padding 1), 1x5 / 5x1 stride 1 (padding
+// (0,2) / (2,0), the separable GRU's gates) and 3x3 stride 2 (padding 1, the encoders' downsampling).
+//
+// Implicit GEMM: out[k, pixel] = sum over (tap, c) of W[k, c, tap] * x[c, stride*pixel + tap].
+//   workgroup = 4 waves: 64 (or 32) output channels x TH rows x 32 columns of one image
+//   wave w    = rows NTW*w .. NTW*w + NTW-1: MT x NTW accumulator tiles of 32 channels x 32 pixels
+//   input channels stream in chunks of 16 (one k-step): the patch of a chunk is split into high and
+//   low parts while it is staged and lies in LDS as [part][k-half][row][column][8 channels] (a lane's
+//   B fragment of any tap is one 16-byte read, lanes on consecutive 16-byte slots; with stride 2 the
+//   even and the odd columns of a row are stored apart so that this still holds);
+//   weights are pre-split and pre-arranged in operand order; a chunk's taps x 4 KiB are copied to LDS
+//   as they are.  The multiply phase reads only LDS; two workgroups share a CU so that one stages
+//   while the other multiplies.
 #include "vo_common.h"
 
 #include <type_traits>
@@ -35,16 +39,30 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CK = 16;                        // input channels per chunk (the k of one matrix instruction)
 constexpr int KB = 64;                        // output channels per workgroup
-constexpr int TH = 16, TW = 32;               // output tile of a workgroup in pixels
-constexpr int PR = TH + 2;                    // patch rows
-constexpr int PC = TW + 4;                    // patch columns [x0 - 2, x0 + 34): 8-byte aligned pairs
-constexpr int PLANE = PR * PC * 16;           // bytes of one (part, k-half) plane: 16 bytes per pixel
+constexpr int TW = 32;                        // output columns of a workgroup's tile (one matrix tile of pixels per row)
 constexpr int NT = 256;                       // threads per workgroup
-constexpr int UNITS = 2 * PR * (PC / 2);      // staging units: (k-half, row, column pair) = 648
-constexpr int ROUNDS = (UNITS + NT - 1) / NT; // 3
 constexpr int A_TAP = 2 * 2 * 64 * 16;        // bytes of weights per (chunk, tap): [part][m-tile][lane][16]
-constexpr int A_CHUNK = 9 * A_TAP;            // 36864
 constexpr int MAX_NORM_C = 256;
+
+// Filter R x S, stride ST; NTW = output rows per wave (TH = 4*NTW rows per workgroup).
+template <int R_, int S_, int ST_, int NTW_>
+struct Geo {
+    static constexpr int R = R_, S = S_, ST = ST_, NTW = NTW_;
+    static constexpr int TAPS = R * S;
+    static constexpr int TH = 4 * NTW;
+    static constexpr int PAD_H = R / 2, PAD_W = S / 2;
+    static constexpr int SLACK = PAD_W & 1;                                   // the patch starts at an even input column
+    static constexpr int PR = (TH - 1) * ST + R;                              // patch rows
+    static constexpr int PC = ((TW - 1) * ST + S + SLACK + 1) / 2 * 2;        // patch columns (even)
+    static constexpr int PLANE = PR * PC * 16;                                // bytes of one (part, k-half) plane
+    static constexpr int UNITS = 2 * PR * (PC / 2);                           // staging units: (k-half, row, column pair)
+    static constexpr int ROUNDS = (UNITS + NT - 1) / NT;
+    static constexpr int A_CHUNK = TAPS * A_TAP;                              // bytes of weights per chunk
+    static constexpr int A_PIECES = (A_CHUNK / 16 + NT - 1) / NT;             // 16-byte pieces per thread and chunk
+    static constexpr int STEPS = TAPS * NTW;                                  // (tap, pixel tile) steps per chunk
+    // position of patch column c inside a row of the LDS image
+    static constexpr int col_pos(int c) { return ST == 1 ? c : (c & 1) * (PC / 2) + (c >> 1); }
+};
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -52,21 +70,21 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, p);
 }
 
-// Weights (K,C,3,3) float32 -> high and low bf16 parts in the register order of the A operand:
+// Weights (K,C,taps) float32 -> high and low bf16 parts in the register order of the A operand:
 //   Ag[kb][chunk][tap][part][mt][lane][j]:  k = kb*64 + mt*32 + (lane & 31),  c = chunk*16 + 8*(lane >> 5) + j
 __global__ __launch_bounds__(256) void filter_split_kernel(const float* __restrict__ g, unsigned short* __restrict__ Ag,
-                                                           int K, int C, int Kpad) {
+                                                           int K, int C, int Kpad, int taps) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Kpad * C) return;
     const int k = (int)(idx / C), c = (int)(idx % C);
     const int kb = k >> 6, mt = (k >> 5) & 1, kl = k & 31, chunk = c >> 4, kg = (c >> 3) & 1, j = c & 7;
     const int nchunks = C / CK;
-    for (int tap = 0; tap < 9; ++tap) {
-        const float w = k < K ? g[((int64_t)k * C + c) * 9 + tap] : 0.0f;
+    for (int tap = 0; tap < taps; ++tap) {
+        const float w = k < K ? g[((int64_t)k * C + c) * taps + tap] : 0.0f;
         const unsigned hi = pack_bf16(w, 0.0f) & 0xffffu;
         const float rest = w - __uint_as_float(hi << 16);
         const unsigned lo = pack_bf16(rest, 0.0f) & 0xffffu;
-        const int64_t base = ((((int64_t)kb * nchunks + chunk) * 9 + tap) * 2) * 2;          // [part][mt]
+        const int64_t base = ((((int64_t)kb * nchunks + chunk) * taps + tap) * 2) * 2;       // [part][mt]
         const int lane = kg * 32 + kl;
         Ag[((base + 0 * 2 + mt) * 64 + lane) * 8 + j] = (unsigned short)hi;
         Ag[((base + 1 * 2 + mt) * 64 + lane) * 8 + j] = (unsigned short)lo;
@@ -77,16 +95,20 @@ struct Epilogue { const float* scale; const float* shift; const float* skip; int
 struct InputNorm { const double* stats; float eps; };
 
 // MT: 32-channel tiles per workgroup (2: 64 output channels; 1: a last block of at most 32).
-template <bool NORM_IN, int MT>
-__global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
-                                                               float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H,
-                                                               int W, int K, int blocks_x, int blocks_y, int kblocks,
-                                                               int kb_base) {
+// H, W: input size; Ho, Wo: output size.
+template <typename G, bool NORM_IN, int MT>
+__global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
+                                                            float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H,
+                                                            int W, int Ho, int Wo, int K, int blocks_x, int blocks_y,
+                                                            int kblocks, int kb_base) {
+    constexpr int PLANE = G::PLANE, PC = G::PC, PR = G::PR, UNITS = G::UNITS, ROUNDS = G::ROUNDS, NTW = G::NTW;
+    constexpr int A_CHUNK = G::A_CHUNK, A_PIECES = G::A_PIECES, TAPS = G::TAPS, STEPS = G::STEPS;
     // patch | weights of the chunk | (NORM_IN) per-channel scale and shift.  The reduction buffer of the
     // statistics epilogue re-uses the patch area after the last chunk.
     __shared__ __align__(16) unsigned char lds[4 * PLANE + A_CHUNK + (NORM_IN ? MAX_NORM_C * 8 : 0)];
     float2* nrm = reinterpret_cast<float2*>(lds + 4 * PLANE + A_CHUNK);
     float* red = reinterpret_cast<float*>(lds);                              // [2][4 waves][64]
+    static_assert(4 * PLANE >= 2 * 4 * 64 * 4, "reduction buffer does not fit the patch area");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid;
@@ -99,8 +121,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
     const int by = bid % blocks_y;
     const int n = bid / blocks_y;
     const int nchunks = C / CK;
-    const int y0 = by * TH, x0 = bx * TW;
-    const int HW4 = H * W * 4;
+    const int y0 = by * G::TH, x0 = bx * TW;                                 // output pixel origin
+    const int HW4 = H * W * 4, HWo4 = Ho * Wo * 4;
 
     const float* xn = x + (int64_t)n * C * H * W;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, C * HW4, 0x00020000);
@@ -114,11 +136,13 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
     for (int i = 0; i < ROUNDS; ++i) {
         const int u = tid + i * NT;
         const int kg = u / (PR * (PC / 2)), rem = u - kg * (PR * (PC / 2)), row = rem / (PC / 2), pr = rem - row * (PC / 2);
-        const int gy = y0 - 1 + row, gx = x0 - 2 + 2 * pr;
+        const int gy = y0 * G::ST - G::PAD_H + row, gx = x0 * G::ST - G::PAD_W - G::SLACK + 2 * pr;
         const bool ok = u < UNITS && gy >= 0 && gy < H && gx >= 0 && gx < W;
         u_off[i] = ok ? ((kg * 8 * H + gy) * W + gx) * 4 : (int)0x80000000;
-        u_lds[i] = kg * PLANE + (row * PC + 2 * pr) * 16;                    // + part * 2 * PLANE
+        // stride 1: the pair's pixels lie side by side; stride 2: the even one in the row's first half, the odd one in its second
+        u_lds[i] = kg * PLANE + (row * PC + (G::ST == 1 ? 2 * pr : pr)) * 16;                // + part * 2 * PLANE
     }
+    constexpr int PX_STEP = G::ST == 1 ? 16 : (PC / 2) * 16;                 // bytes from a pair's first pixel to its second
     if (NORM_IN) {
         const double hw = (double)H * (double)W;
         for (int c = tid; c < C; c += NT) {
@@ -172,31 +196,32 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
                     hi[jj] = h;
                     lo[jj] = pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
                 }
-                *reinterpret_cast<u32x4*>(lds + u_lds[i] + px * 16) = hi;
-                *reinterpret_cast<u32x4*>(lds + 2 * PLANE + u_lds[i] + px * 16) = lo;
+                *reinterpret_cast<u32x4*>(lds + u_lds[i] + px * PX_STEP) = hi;
+                *reinterpret_cast<u32x4*>(lds + 2 * PLANE + u_lds[i] + px * PX_STEP) = lo;
             }
         }
     };
 
-    f32x16 acc[MT][4];
+    f32x16 acc[MT][NTW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
 
     // A fragment of (tap, part, mt): weights area + ((tap*2 + part)*2 + mt) KiB + 16*lane
-    // B fragment of (tap r, s), pixel tile nt: patch row 4*wave + nt + r, patch column (lane & 31) + s + 1
+    // B fragment of (tap r, s), pixel tile nt: patch row (NTW*wave + nt)*stride + r, patch column (lane & 31)*stride + s + slack
     const unsigned char* a_lds = lds + 4 * PLANE + lane * 16;
-    const unsigned char* b_lds = lds + (lane >> 5) * PLANE + ((4 * wave) * PC + (lane & 31) + 1) * 16;
+    const unsigned char* b_lds = lds + (lane >> 5) * PLANE + ((NTW * wave * G::ST) * PC + (lane & 31)) * 16;
     auto read_a = [&](int tap, int part, int mt) {
         return *reinterpret_cast<const bf16x8*>(a_lds + ((tap * 2 + part) * 2 + mt) * 1024);
     };
     auto read_b = [&](int tap, int nt, int part) {
-        return *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PLANE + ((nt + tap / 3) * PC + tap % 3) * 16);
+        const int r = tap / G::S, c = tap % G::S + G::SLACK;                 // lane n reads patch column n*stride + c
+        const int pos = G::ST == 1 ? c : (c & 1) * (PC / 2) + (c >> 1);
+        return *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PLANE + ((nt * G::ST + r) * PC + pos) * 16);
     };
-    constexpr int A_PIECES = A_CHUNK / 16 / NT;                              // 9 sixteen-byte pieces per thread and chunk
 
     // a chunk's weights are a linear copy (they are stored in operand order); they are requested at the
     // end of the previous chunk's multiply phase, so their latency passes under the barrier and the
@@ -206,7 +231,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
         chunk = chunk < nchunks ? chunk : nchunks - 1;
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i)
-            aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ars, (tid + i * NT) * 16, chunk * A_CHUNK, 0);
+            if ((i + 1) * NT * 16 <= A_CHUNK || (tid + i * NT) * 16 < A_CHUNK)
+                aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ars, (tid + i * NT) * 16, chunk * A_CHUNK, 0);
     };
     load_raw(0);
     load_aw(0);
@@ -214,12 +240,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         store_raw(chunk);
 #pragma unroll
-        for (int i = 0; i < A_PIECES; ++i) *reinterpret_cast<u32x4*>(lds + 4 * PLANE + (tid + i * NT) * 16) = aw[i];
+        for (int i = 0; i < A_PIECES; ++i)
+            if ((i + 1) * NT * 16 <= A_CHUNK || (tid + i * NT) * 16 < A_CHUNK)
+                *reinterpret_cast<u32x4*>(lds + 4 * PLANE + (tid + i * NT) * 16) = aw[i];
         __syncthreads();
         load_raw(chunk + 1);                                                 // in flight during the whole multiply phase
 
-        // 36 steps of (tap, pixel tile): 3*MT matrix instructions each, operands double-buffered in
-        // registers: a step issues the reads of the next one (and a quarter of the next tap's weights)
+        // STEPS steps of (tap, pixel tile): 3*MT matrix instructions each, operands double-buffered in
+        // registers: a step issues the reads of the next one (and its share of the next tap's weights)
         bf16x8 fa[2][2][MT], fb[2][2];
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
@@ -227,14 +255,19 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
             for (int mt = 0; mt < MT; ++mt) fa[0][part][mt] = read_a(0, part, mt);
             fb[0][part] = read_b(0, 0, part);
         }
+        constexpr int A_PER_STEP = (2 * MT + NTW - 1) / NTW;                 // weight fragments fetched per step
 #pragma unroll
-        for (int st = 0; st < 36; ++st) {
-            const int tap = st >> 2, nt = st & 3, ca = tap & 1, cb = st & 1;
-            if (st + 1 < 36) {
-                fb[cb ^ 1][0] = read_b((st + 1) >> 2, (st + 1) & 3, 0);
-                fb[cb ^ 1][1] = read_b((st + 1) >> 2, (st + 1) & 3, 1);
+        for (int st = 0; st < STEPS; ++st) {
+            const int tap = st / NTW, nt = st % NTW, ca = tap & 1, cb = st & 1;
+            if (st + 1 < STEPS) {
+                fb[cb ^ 1][0] = read_b((st + 1) / NTW, (st + 1) % NTW, 0);
+                fb[cb ^ 1][1] = read_b((st + 1) / NTW, (st + 1) % NTW, 1);
             }
-            if (tap + 1 < 9 && nt < 2 * MT) fa[ca ^ 1][nt / MT][nt % MT] = read_a(tap + 1, nt / MT, nt % MT);
+            if (tap + 1 < TAPS) {
+#pragma unroll
+                for (int f = nt * A_PER_STEP; f < (nt + 1) * A_PER_STEP && f < 2 * MT; ++f)
+                    fa[ca ^ 1][f / MT][f % MT] = read_a(tap + 1, f / MT, f % MT);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 // the small terms first, so that they are not rounded away against the large one
@@ -243,7 +276,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
             }
             // the step's reads first (they feed the NEXT step), then its matrix instructions
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + A_PER_STEP, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -253,11 +286,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
 
     // Epilogue.  C/D layout of the 32x32 tile: pixel = lane & 31, channel row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
     float* yn = y + (int64_t)n * ep.y_batch_stride;
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yn, 0, K * HW4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yn, 0, K * HWo4, 0x00020000);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(ep.skip ? ep.skip + (int64_t)n * K * H * W : x), 0, ep.skip ? K * HW4 : 0, 0x00020000);
+        const_cast<float*>(ep.skip ? ep.skip + (int64_t)n * K * Ho * Wo : x), 0, ep.skip ? K * HWo4 : 0, 0x00020000);
     const int col = x0 + (lane & 31), lh = lane >> 5;
-    const int row0 = y0 + 4 * wave;
+    const int row0 = y0 + NTW * wave;
 
     if (ep.stats) {
         // plane sums of the raw output: per lane over its four rows, then over the 32 pixel lanes by a
@@ -271,8 +304,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
             for (int e = 0; e < 16; ++e) {
                 s1[e] = 0.0f; s2[e] = 0.0f;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const bool ok = row0 + nt < H && col < W;
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const bool ok = row0 + nt < Ho && col < Wo;
                     const float v = ok ? acc[mt][nt][e] : 0.0f;
                     s1[e] += v; s2[e] = fmaf(v, v, s2[e]);
                 }
@@ -322,13 +355,13 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
             const bool kok = k < K;
             sc[e] = 1.0f; sh[e] = 0.0f;
             if (ep.shift && kok) { sc[e] = ep.scale ? ep.scale[k] : 1.0f; sh[e] = ep.shift[k]; }
-            koff[e] = kok ? k * HW4 : (int)0x80000000;
+            koff[e] = kok ? k * HWo4 : (int)0x80000000;
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const int row = row0 + nt;
-            const bool pok = row < H && col < W;
-            const int poff = (row * W + col) * 4;
+            const bool pok = row < Ho && col < Wo;
+            const int poff = (row * Wo + col) * 4;
             float sk[16];
             if (ep.skip) {
 #pragma unroll
@@ -347,58 +380,101 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(const float* __re
     }
 }
 
-}  // namespace
 
-extern "C" int vo_conv3x3_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream) {
-    VO_REQUIRE(weight && arranged, "vo_conv3x3_bf16x3_filter: null pointer");
-    VO_REQUIRE(K > 0 && C > 0, "vo_conv3x3_bf16x3_filter: bad sizes K=%d C=%d", K, C);
-    if (C % CK != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3_filter: C=%d is not a multiple of %d", C, CK);
+// ---------------------------------------------------------------------------------------------------
+// host side
+
+int split_filter(const char* name, const float* weight, void* arranged, int K, int C, int taps, hipStream_t st) {
+    if (!weight || !arranged) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if (K <= 0 || C <= 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes K=%d C=%d", name, K, C);
+    if (C % CK != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: C=%d is not a multiple of %d", name, C, CK);
     const int Kpad = (K + KB - 1) / KB * KB;
     const int64_t n = (int64_t)Kpad * C;
-    filter_split_kernel<<<dim3((unsigned)vo_ceil_div(n, 256)), dim3(256), 0, vo_stream(stream)>>>(
-        weight, static_cast<unsigned short*>(arranged), K, C, Kpad);
-    VO_CHECK_LAUNCH("vo_conv3x3_bf16x3_filter");
+    filter_split_kernel<<<dim3((unsigned)vo_ceil_div(n, 256)), dim3(256), 0, st>>>(weight, static_cast<unsigned short*>(arranged), K,
+                                                                                 C, Kpad, taps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;
 }
 
-extern "C" int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
-                                 const float* scale, const float* shift, int relu, const float* skip, double* stats,
-                                 const double* in_stats, float in_eps, int N, int C, int H, int W, int K, void* stream) {
-    VO_REQUIRE(x && arranged && y, "vo_conv3x3_bf16x3: null pointer");
-    VO_REQUIRE(!scale || shift, "vo_conv3x3_bf16x3: scale without shift");
-    VO_REQUIRE(!stats || (!shift && !relu && !skip), "vo_conv3x3_bf16x3: statistics are of the raw output, no epilogue with them");
-    VO_REQUIRE(skip != y, "vo_conv3x3_bf16x3: skip must not alias the output");
-    VO_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && K > 0, "vo_conv3x3_bf16x3: bad sizes");
-    if (y_batch_stride == 0) y_batch_stride = (int64_t)K * H * W;
-    VO_REQUIRE(y_batch_stride >= (int64_t)K * H * W, "vo_conv3x3_bf16x3: y_batch_stride smaller than one item");
-    if (C % CK != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: C=%d is not a multiple of %d", C, CK);
+template <typename G>
+int launch_conv(const char* name, const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
+                const float* shift, int relu, const float* skip, double* stats, const double* in_stats, float in_eps, int N,
+                int C, int H, int W, int K, hipStream_t st) {
+    if (!x || !arranged || !y) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if (scale && !shift) return vo_fail(VO_ERR_INVALID_ARG, "%s: scale without shift", name);
+    if (stats && (shift || relu || skip))
+        return vo_fail(VO_ERR_INVALID_ARG, "%s: statistics are of the raw output, no epilogue with them", name);
+    if (skip == y) return vo_fail(VO_ERR_INVALID_ARG, "%s: skip must not alias the output", name);
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes", name);
+    const int Ho = (H - 1) / G::ST + 1, Wo = (W - 1) / G::ST + 1;
+    if (y_batch_stride == 0) y_batch_stride = (int64_t)K * Ho * Wo;
+    if (y_batch_stride < (int64_t)K * Ho * Wo) return vo_fail(VO_ERR_INVALID_ARG, "%s: y_batch_stride smaller than one item", name);
+    if (C % CK != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: C=%d is not a multiple of %d", name, C, CK);
     if (W % 2 != 0 || (reinterpret_cast<uintptr_t>(x) & 7) != 0)
-        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: needs an even width and an 8-byte aligned input (W=%d)", W);
-    if ((int64_t)C * H * W * 4 >= 0x7fffffffLL || (int64_t)K * H * W * 4 >= 0x7fffffffLL)
-        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: one image of the input or output exceeds 2 GiB");
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: needs an even width and an 8-byte aligned input (W=%d)", name, W);
+    if ((int64_t)C * H * W * 4 >= 0x7fffffffLL || (int64_t)K * Ho * Wo * 4 >= 0x7fffffffLL)
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: one image of the input or output exceeds 2 GiB", name);
     if (in_stats && C > MAX_NORM_C)
-        return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: normalise-on-load supports at most %d input channels", MAX_NORM_C);
-    const int bx = (W + TW - 1) / TW, by = (H + TH - 1) / TH;
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: normalise-on-load supports at most %d input channels", name, MAX_NORM_C);
+    const int bx = (Wo + TW - 1) / TW, by = (Ho + G::TH - 1) / G::TH;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
-    if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv3x3_bf16x3: grid too large");
+    if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
     const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats};
     const InputNorm nrm{in_stats, in_eps};
     const unsigned short* ag = static_cast<const unsigned short*>(arranged);
     // a last block with at most 32 channels goes out as a launch of its own with one channel tile
     const int rem = K % KB;
     const int full = (rem >= 1 && rem <= 32) ? kblocks - 1 : kblocks;
-    hipStream_t st = vo_stream(stream);
     if (full > 0) {
         const dim3 grid((unsigned)(blocks * full));
-        if (in_stats) conv3x3_bf16x3_kernel<true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, full, 0);
-        else conv3x3_bf16x3_kernel<false, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, full, 0);
+        if (in_stats) conv_bf16x3_kernel<G, true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0);
+        else conv_bf16x3_kernel<G, false, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0);
     }
     if (full < kblocks) {
         const dim3 grid((unsigned)blocks);
-        if (in_stats) conv3x3_bf16x3_kernel<true, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, 1, full);
-        else conv3x3_bf16x3_kernel<false, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, K, bx, by, 1, full);
+        if (in_stats) conv_bf16x3_kernel<G, true, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full);
+        else conv_bf16x3_kernel<G, false, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full);
     }
-    VO_CHECK_LAUNCH("vo_conv3x3_bf16x3");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;
+}
+
+using Geo3x3 = Geo<3, 3, 1, 4>;
+using Geo1x5 = Geo<1, 5, 1, 4>;
+using Geo5x1 = Geo<5, 1, 1, 4>;
+using Geo3x3s2 = Geo<3, 3, 2, 1>;
+
+}  // namespace
+
+extern "C" int vo_conv3x3_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream) {
+    return split_filter("vo_conv3x3_bf16x3_filter", weight, arranged, K, C, 9, vo_stream(stream));
+}
+
+extern "C" int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
+                                 const float* scale, const float* shift, int relu, const float* skip, double* stats,
+                                 const double* in_stats, float in_eps, int N, int C, int H, int W, int K, void* stream) {
+    return launch_conv<Geo3x3>("vo_conv3x3_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, skip, stats, in_stats,
+                               in_eps, N, C, H, W, K, vo_stream(stream));
+}
+
+extern "C" int vo_conv5_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream) {
+    return split_filter("vo_conv5_bf16x3_filter", weight, arranged, K, C, 5, vo_stream(stream));
+}
+
+extern "C" int vo_conv5_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
+                               const float* shift, int relu, int N, int C, int H, int W, int K, int vertical, void* stream) {
+    if (vertical)
+        return launch_conv<Geo5x1>("vo_conv5_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr,
+                                   0.0f, N, C, H, W, K, vo_stream(stream));
+    return launch_conv<Geo1x5>("vo_conv5_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr, 0.0f,
+                               N, C, H, W, K, vo_stream(stream));
+}
+
+extern "C" int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y, const float* scale, const float* shift,
+                                   int relu, double* stats, int N, int C, int H, int W, int K, void* stream) {
+    return launch_conv<Geo3x3s2>("vo_conv3x3s2_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, stats, nullptr, 0.0f, N, C,
+                                 H, W, K, vo_stream(stream));
 }

@@ -323,6 +323,66 @@ def conv5_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, vertical:
     return out
 
 
+def conv5_split_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,1,5) or (K,C,5,1) float32 weight -> bf16 high/low parts in operand order for conv5_split
+    (a float32 tensor used as raw storage).  C must be a multiple of 16."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) not in ((1, 5), (5, 1)):
+        raise ValueError("weight must be (K,C,1,5) or (K,C,5,1)")
+    K, C = weight.shape[:2]
+    if C % 16:
+        raise ValueError("the split-bf16 path needs a multiple of 16 input channels")
+    out = torch.empty(((K + 63) // 64 * 64 * C * 5,), device=weight.device, dtype=torch.float32)
+    _call("vo_conv5_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
+    return out
+
+
+def conv5_split(x: torch.Tensor, arranged: torch.Tensor, K: int, vertical: bool, scale: torch.Tensor | None = None,
+                shift: torch.Tensor | None = None, relu: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """conv5_winograd's convolution (1x5 / 5x1, stride 1, "same") on the split-bf16 direct kernel, with
+    an optional fused v*scale[k] + shift[k] / ReLU and a channel-slice output."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C * 5:
+        raise ValueError("arranged weights do not match (K, C)")
+    if W % 2:
+        raise ValueError("the split-bf16 kernel needs an even width")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    if out is None:
+        out = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (N, K, H, W) or out.dtype != torch.float32:
+        raise ValueError("out must be float32 (N,K,H,W)")
+    py, sy = _slice(out, "out")
+    _call("vo_conv5_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), py, sy,
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K,
+          int(bool(vertical)), _stream(), nbytes=4 * (x.numel() + out.numel()), flops=2 * 15 * N * K * C * H * W)
+    return out
+
+
+def conv3x3s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+                    shift: torch.Tensor | None = None, relu: bool = False, stats: torch.Tensor | None = None) -> torch.Tensor:
+    """conv2d(x, weight, stride=2, padding=1) on the split-bf16 direct kernel (weights from
+    conv3x3_split_filter), optional epilogue, or ``stats`` (zeroed float64 (N,K,2)) receiving the plane
+    sums of the raw output."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C * 9:
+        raise ValueError("arranged weights do not match (K, C)")
+    if W % 2:
+        raise ValueError("the split-bf16 kernel needs an even width")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    if stats is not None and (stats.numel() != N * K * 2 or shift is not None or relu):
+        raise ValueError("stats must be (N,K,2) float64 and excludes the epilogue")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
+    _call("vo_conv3x3s2_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
+          _opt(stats, "stats", torch.float64), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * 27 * N * K * C * Ho * Wo)
+    return out
+
+
 def conv1x1_filter(weight: torch.Tensor) -> torch.Tensor:
     """(K,C,1,1) or (K,C) float32 weight -> the arranged weights conv1x1 consumes."""
     if weight.dim() not in (2, 4) or (weight.dim() == 4 and tuple(weight.shape[2:]) != (1, 1)):

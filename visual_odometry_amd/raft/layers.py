@@ -73,6 +73,9 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
             Wg = _conv7x7_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv7x7(x, Wg, conv.out_channels, None, conv.bias, False, conv.stride[0])
+            Us = _split_s2_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Us is not None:
+                return ops.conv3x3s2_split(x, Us, conv.out_channels, None, conv.bias, False)
             Wg = _conv3x3s2_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv3x3s2(x, Wg, conv.out_channels, None, conv.bias, False)
@@ -231,6 +234,29 @@ def _conv3x3s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, paddin
     return cached[1]
 
 
+def _split_s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
+    """The cached split-bf16 weights when this 3x3 stride-2 convolution can run on the split-bf16 direct
+    kernel (float32, input channels a multiple of 16, even input width, an output width that fills
+    the kernel's 32-pixel row segments to at least 60 %), else None."""
+    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+            and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2)
+            and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
+            and x.shape[1] % 16 == 0 and x.shape[3] % 2 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
+        return None
+    wo = (x.shape[3] - 1) // 2 + 1
+    if wo < 0.6 * ((wo + 31) // 32 * 32):
+        return None
+    key = (weight._version, weight.data_ptr())
+    table = getattr(weight, "_vo_winograd", None)            # the split filter of a 3x3 weight is shared with stride 1
+    if table is None or table[0] != key:
+        table = (key, {})
+        weight._vo_winograd = table
+    U = table[1].get(1)
+    if U is None:
+        U = table[1][1] = ops.conv3x3_split_filter(weight.contiguous())
+    return U
+
+
 def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
                   groups: int = 1) -> torch.Tensor:
     """Bias-free convolution inside the fused path: eligible 3x3 layers on the Winograd
@@ -244,6 +270,9 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     Wg = _conv7x7_weights_for(x, weight, stride, padding, dilation, groups)
     if Wg is not None:
         return ops.conv7x7(x, Wg, weight.shape[0], stride=tuple(stride)[0])
+    Us = _split_s2_weights_for(x, weight, stride, padding, dilation, groups)
+    if Us is not None:
+        return ops.conv3x3s2_split(x, Us, weight.shape[0])
     Wg = _conv3x3s2_weights_for(x, weight, stride, padding, dilation, groups)
     if Wg is not None:
         return ops.conv3x3s2(x, Wg, weight.shape[0])
@@ -252,8 +281,15 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
             and tuple(dilation) == (1, 1) and groups == 1 and x.dtype == torch.float32 and weight.dtype == torch.float32
             and x.is_cuda and x.is_contiguous() and weight.shape[1] % 8 == 0 and weight.shape[0] >= 32
             and weight.shape[1] == x.shape[1]):
-        # the separable GRU's gate convolutions: one-dimensional Winograd F(4,5) on the matrix cores
         key = (weight._version, weight.data_ptr())
+        if _SPLIT_BF16 and weight.shape[1] % 16 == 0 and x.shape[3] % 2 == 0:
+            # the separable GRU's gate convolutions on the split-bf16 direct kernel
+            cached = getattr(weight, "_vo_conv5_split", None)
+            if cached is None or cached[0] != key:
+                cached = (key, ops.conv5_split_filter(weight))
+                weight._vo_conv5_split = cached
+            return ops.conv5_split(x, cached[1], weight.shape[0], ks == (5, 1))
+        # ... or as one-dimensional Winograd F(4,5) on the float32 matrix instructions
         cached = getattr(weight, "_vo_winograd1d", None)
         if cached is None or cached[0] != key:
             cached = (key, ops.winograd1d_filter(weight))
@@ -280,6 +316,9 @@ def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor
             Wg = _conv7x7_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv7x7(x, Wg, w.shape[0], scale, shift, relu, conv.stride[0])
+            Us = _split_s2_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Us is not None:
+                return ops.conv3x3s2_split(x, Us, w.shape[0], scale, shift, relu)
             Wg = _conv3x3s2_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv3x3s2(x, Wg, w.shape[0], scale, shift, relu)
@@ -332,6 +371,12 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
                 # the convolution's store accumulates the plane statistics: the norm is one pass
                 stats = torch.zeros((x.shape[0], w.shape[0], 2), device=x.device, dtype=torch.float64)
                 y = ops.conv3x3_winograd(x, U, w.shape[0], stats=stats)
+                return ops.instance_norm_apply_(y, stats, norm.eps, relu, skip)
+            Us = _split_s2_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Us is not None and x.shape[0] * w.shape[0] <= 65535:
+                # the downsampling layers too leave their plane statistics
+                stats = torch.zeros((x.shape[0], w.shape[0], 2), device=x.device, dtype=torch.float64)
+                y = ops.conv3x3s2_split(x, Us, w.shape[0], stats=stats)
                 return ops.instance_norm_apply_(y, stats, norm.eps, relu, skip)
             return ops.instance_norm_relu_(_conv_nobias(x, conv), norm.eps, relu, skip)
         if isinstance(norm, nn.BatchNorm2d) and not norm.training and norm.track_running_stats:
