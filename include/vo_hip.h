@@ -47,6 +47,13 @@ const char* vo_last_error(void);
 int vo_prepare_images(const uint8_t* gray, float* out, int frames, int H, int W,
                       int pad_left, int pad_right, int pad_top, int pad_bottom,
                       int normalize, void* stream);
+/* The same with ONE output plane per frame, out (frames,1,H+pt+pb,W+pl+pr): the three channels the
+ * wrappers build from a gray frame are equal (flow/flow_map_RAFT.py:96,101-102), so the first
+ * convolution of every encoder may run on one plane with its filter summed over the input channels
+ * (sum_c w[k,c]*x = (sum_c w[k,c])*x): a third of the stems' multiplications. */
+int vo_prepare_images_gray(const uint8_t* gray, float* out, int frames, int H, int W,
+                           int pad_left, int pad_right, int pad_top, int pad_bottom,
+                           int normalize, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Stereo rectification (stereo/stereo_rectification.py; the reference calls OpenCV).

@@ -244,6 +244,25 @@ def test_raft_stereo_end_to_end(vo, H, W, iters, realtime):
     assert float(disp.abs().max()) > 1e-3
 
 
+def test_gray_stem_equals_three_equal_channels(vo):
+    """Encoders fed the single plane of a gray frame (stem filter summed over its input channels) against
+    the same encoders fed three equal channels: rounding-level differences only."""
+    from visual_odometry_amd.raft.layers import BasicEncoder, MultiBasicEncoder, fused_passes, gray_stem
+    torch.manual_seed(3)
+    for enc, kw in ((BasicEncoder(256, "instance", 3), {}), (BasicEncoder(256, "instance", 2), {}),
+                    (MultiBasicEncoder([[64, 64, 64], [64, 64, 64]], "batch", 2), {"num_layers": 2})):
+        enc = enc.to(DEV).eval()
+        g = _rand(2, 1, 96, 128, seed=30).to(DEV)
+        with torch.no_grad(), fused_passes():
+            a = enc(g, **kw)
+            b = enc(g.expand(-1, 3, -1, -1).contiguous(), **kw)
+        flat = lambda o: torch.cat([t.flatten() for t in (o if not torch.is_tensor(o) else [o]) for t in (t if not torch.is_tensor(t) else [t])]) if not torch.is_tensor(o) else o.flatten()
+        fa, fb = flat(a), flat(b)
+        assert (fa - fb).abs().max().item() < 1e-4 * max(1.0, fb.abs().max().item())
+        assert gray_stem(enc.conv1, g) is not enc.conv1 and gray_stem(enc.conv1, g) is gray_stem(enc.conv1, g)
+        assert gray_stem(enc.conv1, g.expand(-1, 3, -1, -1)) is enc.conv1
+
+
 def test_plugin_wrappers(vo):
     from visual_odometry_amd import synthetic as syn
     from visual_odometry_amd.raft.models import RAFTStereoConfig
@@ -282,6 +301,8 @@ def test_prepare_images_matches_host_input_stage(vo, F, H, W, div):
     assert torch.equal(got.cpu(), 2 * (ref_img / 255.0) - 1.0)
     raw, _ = ops.prepare_images(gray.to(DEV), div, normalize=False)
     assert torch.equal(raw.cpu(), ref_img)
+    one, pads1 = ops.prepare_images(gray.to(DEV), div, normalize=True, channels=1)      # the plane the three channels equal
+    assert pads1 == pads and one.shape[1] == 1 and torch.equal(one, got[:, :1])
     assert torch.equal(raft_ref.unpad(raw.cpu(), pads), rgb)
 
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vo_gru_gates": [_P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _L, _I, _P],
     "vo_gru_update": [_P, _P, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _I, _L, _I, _P],
     "vo_prepare_images": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_prepare_images_gray": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_corr_volume_2d": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_1d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_corr_pyramid_2d": [_P, _P, _P, _P, _L, _I, _I, _P],

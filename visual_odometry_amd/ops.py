@@ -576,16 +576,19 @@ def pad_amounts(ht: int, wd: int, divis_by: int):
     return [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
 
 
-def prepare_images(gray: torch.Tensor, divis_by: int = 8, normalize: bool = True):
-    """(F,H,W) uint8 GPU frames -> ((F,3,Hp,Wp) float32, pads): three equal channels,
-    replicate padding to a multiple of ``divis_by``, optional 2*(x/255)-1."""
+def prepare_images(gray: torch.Tensor, divis_by: int = 8, normalize: bool = True, channels: int = 3):
+    """(F,H,W) uint8 GPU frames -> ((F,channels,Hp,Wp) float32, pads): three equal channels (or, with
+    ``channels=1``, the one plane they all equal), replicate padding to a multiple of ``divis_by``,
+    optional 2*(x/255)-1."""
     if gray.dim() != 3:
         raise ValueError("gray frames must be (F,H,W)")
+    if channels not in (1, 3):
+        raise ValueError("channels must be 1 or 3")
     F_, H, W = gray.shape
     pads = pad_amounts(H, W, divis_by)
-    out = torch.empty((F_, 3, H + pads[2] + pads[3], W + pads[0] + pads[1]), device=gray.device, dtype=torch.float32)
-    _call("vo_prepare_images", _dev(gray, "gray", torch.uint8), out.data_ptr(), F_, H, W, *pads,
-          int(bool(normalize)), _stream(), nbytes=gray.numel() + 4 * out.numel())
+    out = torch.empty((F_, channels, H + pads[2] + pads[3], W + pads[0] + pads[1]), device=gray.device, dtype=torch.float32)
+    _call("vo_prepare_images" if channels == 3 else "vo_prepare_images_gray", _dev(gray, "gray", torch.uint8), out.data_ptr(),
+          F_, H, W, *pads, int(bool(normalize)), _stream(), nbytes=gray.numel() + 4 * out.numel())
     return out, pads
 
 

@@ -423,6 +423,29 @@ def add_act(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return torch.relu(x + y)
 
 
+def gray_stem(conv: nn.Conv2d, x: torch.Tensor) -> nn.Conv2d:
+    """The stem convolution for a ONE-plane input.  The wrappers replicate a gray frame into three equal
+    channels (flow/flow_map_RAFT.py:96,101-102); for such an input sum_c w[k,c]*x[c] = (sum_c w[k,c])*x, so
+    the stem runs on the single plane with its filter summed over the input channels: a third of the
+    multiplications of the networks' most expensive few-channel layers.  Returns ``conv`` itself for a
+    three-channel input, else a cached single-channel twin (rebuilt when the weights change or move)."""
+    if x.shape[1] == conv.in_channels or x.shape[1] != 1:
+        return conv
+    key = (conv.weight._version, conv.weight.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()))
+    cached = getattr(conv, "_vo_gray_twin", None)
+    if cached is None or cached[0] != key:
+        twin = nn.Conv2d(1, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=conv.bias is not None)
+        twin = twin.to(conv.weight.device)
+        with torch.no_grad():
+            twin.weight.copy_(conv.weight.sum(dim=1, keepdim=True))
+            if conv.bias is not None:
+                twin.bias.copy_(conv.bias)
+        twin.eval()
+        cached = (key, twin)
+        object.__setattr__(conv, "_vo_gray_twin", cached)          # not a registered sub-module: it holds no state of its own
+    return cached[1]
+
+
 def _norm(kind: str, planes: int) -> nn.Module:
     if kind == "group":
         return nn.GroupNorm(num_groups=planes // 8, num_channels=planes)
@@ -521,8 +544,9 @@ class BasicEncoder(nn.Module):
         return blocks
 
     def forward(self, x: torch.Tensor, pixel_major: bool = False) -> torch.Tensor:
-        """``pixel_major``: return float32 (B,H,W,D) instead of (B,D,H,W)."""
-        x = conv_norm_act(x, self.conv1, self.norm1, True)
+        """``pixel_major``: return float32 (B,H,W,D) instead of (B,D,H,W).  x: three channels, or the
+        one plane of a gray frame."""
+        x = conv_norm_act(x, gray_stem(self.conv1, x), self.norm1, True)
         x = self.layer3(self.layer2(self.layer1(x)))
         return conv_pixel_major(x, self.conv2) if pixel_major else conv_plain(x, self.conv2)
 
@@ -559,7 +583,7 @@ class MultiBasicEncoder(nn.Module):
         return blocks
 
     def forward(self, x: torch.Tensor, num_layers: int = 3):
-        x = conv_norm_act(x, self.conv1, self.norm1, True)
+        x = conv_norm_act(x, gray_stem(self.conv1, x), self.norm1, True)
         x = self.layer3(self.layer2(self.layer1(x)))
         out08 = [conv_plain(f[0](x), f[1]) for f in self.outputs08]
         if num_layers == 1:

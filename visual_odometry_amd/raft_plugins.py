@@ -105,9 +105,10 @@ class HipOpticalFlowRAFT(OpticalFlowInterface):
 
     def compute_flow_sequence(self, gray: torch.Tensor) -> torch.Tensor:
         """(F,H,W) uint8 GPU frames -> (F-1,2,H,W) flow between consecutive frames.
-        The input stage (3-channel replication, padding, normalisation) is one HIP
-        kernel and the feature encoder runs once per frame, not twice per pair."""
-        imgs, pads = ops.prepare_images(gray, 8, normalize=True)
+        The input stage (padding, normalisation) is one HIP kernel, the three equal channels of a gray
+        frame stay one plane (the stems sum their filters over the input channels instead), and the
+        feature encoder runs once per frame, not twice per pair."""
+        imgs, pads = ops.prepare_images(gray, 8, normalize=True, channels=1)
         fm = self.model.features(imgs)
         _, flow_up = self.model(imgs[:-1], imgs[1:], iters=self.iters, fmap1=fm[:-1], fmap2=fm[1:], normalized=True)
         return _unpad(flow_up, pads).contiguous() if any(pads) else flow_up
@@ -156,8 +157,8 @@ class HipDisparityRAFT(StereoDisparityInterface):
 
     def compute_disparity_gray_batch(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
         """(F,H,W) uint8 GPU frames -> disparity (F,H,W) float32; input stage on the GPU."""
-        image1, pads = ops.prepare_images(left, 32, normalize=True)
-        image2, _ = ops.prepare_images(right, 32, normalize=True)
+        image1, pads = ops.prepare_images(left, 32, normalize=True, channels=1)
+        image2, _ = ops.prepare_images(right, 32, normalize=True, channels=1)
         _, disp = self.model(image1, image2, iters=self.iters, normalized=True)
         disp = _unpad(disp, pads) if any(pads) else disp
         return disp[:, 0].contiguous()
