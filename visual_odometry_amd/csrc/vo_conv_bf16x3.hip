@@ -107,8 +107,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     // statistics epilogue re-uses the patch area after the last chunk.
     __shared__ __align__(16) unsigned char lds[4 * PLANE + A_CHUNK + (NORM_IN ? MAX_NORM_C * 8 : 0)];
     float2* nrm = reinterpret_cast<float2*>(lds + 4 * PLANE + A_CHUNK);
-    float* red = reinterpret_cast<float*>(lds);                              // [2][4 waves][64]
-    static_assert(4 * PLANE >= 2 * 4 * 64 * 4, "reduction buffer does not fit the patch area");
+    double* red = reinterpret_cast<double*>(lds);                            // [2][4 waves][64]
+    static_assert(4 * PLANE >= 4 * 4096, "the epilogue's transposition slots and the reduction buffer do not fit the patch area");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid;
@@ -299,16 +299,19 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         // atomics per channel and workgroup
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            float s1[16], s2[16];
+            // float32 only over the lane's own few pixels; everything across lanes in float64, so that the
+            // variance E[x^2] - mean^2 formed from these sums survives planes whose mean dwarfs their spread
+            double s1[16], s2[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                s1[e] = 0.0f; s2[e] = 0.0f;
+                float a1 = 0.0f, a2 = 0.0f;
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const bool ok = row0 + nt < Ho && col < Wo;
                     const float v = ok ? acc[mt][nt][e] : 0.0f;
-                    s1[e] += v; s2[e] = fmaf(v, v, s2[e]);
+                    a1 += v; a2 = fmaf(v, v, a2);
                 }
+                s1[e] = (double)a1; s2[e] = (double)a2;
             }
             // 16 values on 32 lanes -> lane l (of 32) ends with the total of value (l & 15)
 #pragma unroll
@@ -318,8 +321,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 const bool upper = (lane & m) != 0;
 #pragma unroll
                 for (int i = 0; i < keep; ++i) {
-                    const float mine1 = upper ? s1[i + keep] : s1[i], send1 = upper ? s1[i] : s1[i + keep];
-                    const float mine2 = upper ? s2[i + keep] : s2[i], send2 = upper ? s2[i] : s2[i + keep];
+                    const double mine1 = upper ? s1[i + keep] : s1[i], send1 = upper ? s1[i] : s1[i + keep];
+                    const double mine2 = upper ? s2[i + keep] : s2[i], send2 = upper ? s2[i] : s2[i + keep];
                     s1[i] = mine1 + __shfl_xor(send1, m, VO_WAVE);
                     s2[i] = mine2 + __shfl_xor(send2, m, VO_WAVE);
                 }
@@ -338,11 +341,66 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         __syncthreads();
         if (tid < 2 * 32 * MT) {
             const int which = tid / (32 * MT), krow = tid - which * (32 * MT);
-            const float* rp = red + which * 4 * 64 + krow;
-            const double tot = (double)rp[0] + (double)rp[64] + (double)rp[128] + (double)rp[192];
+            const double* rp = red + which * 4 * 64 + krow;
+            const double tot = (rp[0] + rp[64]) + (rp[128] + rp[192]);
             const int k = kb * KB + krow;
             if (k < K) atomicAdd(ep.stats + ((int64_t)n * K + k) * 2 + which, tot);
         }
+    }
+
+    // Wide path: every tile passes through a 4 KiB LDS slot of its wave (32 channels x 32 pixels), so that a
+    // lane ends up with four consecutive pixels of one channel: 16-byte stores (and residual loads), a
+    // quarter of the store instructions, each wave-instruction covering eight full 128-byte segments.
+    // Needs rows that keep 16-byte alignment; otherwise the accumulator layout is stored as it is.
+    const bool wide = (Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ep.y_batch_stride & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(ep.skip) & 15) == 0;
+    if (wide) {
+        if (ep.stats) __syncthreads();                                       // the reduction buffer lies in the same area
+        float* slot = reinterpret_cast<float*>(lds) + wave * 1024;
+        const int q = lane >> 3, px4 = (lane & 7) * 4;                       // read-back role: channel rows q + 8j, pixels px4..px4+3
+        const int colw = x0 + px4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float sc[4], sh[4];
+            int koff[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb * KB + mt * 32 + q + 8 * j;
+                const bool kok = k < K;
+                sc[j] = 1.0f; sh[j] = 0.0f;
+                if (ep.shift && kok) { sc[j] = ep.scale ? ep.scale[k] : 1.0f; sh[j] = ep.shift[k]; }
+                koff[j] = kok ? k * HWo4 : (int)0x80000000;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int row = row0 + nt;
+                const bool pok = row < Ho && colw < Wo;
+                const int poff = (row * Wo + colw) * 4;
+                u32x4 sk[4];
+                if (ep.skip) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        sk[j] = __builtin_amdgcn_raw_buffer_load_b128(srs, (pok && koff[j] >= 0) ? koff[j] + poff : (int)0x80000000, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) slot[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + (lane & 31)] = acc[mt][nt][e];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = *reinterpret_cast<const float4*>(slot + (q + 8 * j) * 32 + px4);
+                    float v[4] = {t.x, t.y, t.z, t.w};
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (ep.shift) v[i] = fmaf(v[i], sc[j], sh[j]);
+                        if (ep.relu) v[i] = fmaxf(v[i], 0.0f);
+                        if (ep.skip) v[i] = fmaxf(v[i] + __uint_as_float(sk[j][i]), 0.0f);
+                        o[i] = __float_as_uint(v[i]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (pok && koff[j] >= 0) ? koff[j] + poff : (int)0x80000000, 0, 0);
+                }
+            }
+        }
+        return;
     }
 
 #pragma unroll

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void instnorm_kernel(T* __restrict__ x, const 
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(T* __restrict__ x, const T* __restrict__ skip,
                                                              const double* __restrict__ stats, int64_t hw, float eps,
-                                                             int relu) {
-    const int64_t plane = blockIdx.y;
+                                                             int relu, int64_t plane0) {
+    const int64_t plane = plane0 + blockIdx.y;
     const double mean = stats[2 * plane] / (double)hw;
     double var = stats[2 * plane + 1] / (double)hw - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void affine_kernel(T* __restrict__ x, const float* __restrict__ scale,
                                                      const float* __restrict__ shift, const T* __restrict__ skip,
-                                                     int C, int64_t hw, int relu) {
-    const int64_t plane = blockIdx.y;
+                                                     int C, int64_t hw, int relu, int64_t plane0) {
+    const int64_t plane = plane0 + blockIdx.y;
     const float a = scale[plane % C], b = shift[plane % C];
     T* p = x + plane * hw;
     const T* q = skip ? skip + plane * hw : nullptr;
@@ -299,15 +299,17 @@ extern "C" int vo_instance_norm_apply(void* x, const void* skip, const double* s
     VO_REQUIRE(x && stats, "vo_instance_norm_apply: null pointer");
     VO_REQUIRE(planes > 0 && hw > 0, "vo_instance_norm_apply: bad sizes");
     if (int rc = check_dtype("vo_instance_norm_apply", dtype)) return rc;
-    if (planes > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_instance_norm_apply: more than 65535 planes");
     int64_t bx = vo_ceil_div(vo_ceil_div(hw, 4), 256);
     if (bx > 64) bx = 64;
-    const dim3 grid((unsigned)bx, (unsigned)planes);
-    if (dtype == VO_F16)
-        instnorm_apply_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, (const __half*)skip, stats, hw, eps, relu);
-    else
-        instnorm_apply_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, stats, hw, eps, relu);
-    VO_CHECK_LAUNCH("vo_instance_norm_apply");
+    // planes ride on grid.y, which holds at most 65535: larger tensors go out in slices
+    for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+        const dim3 grid((unsigned)bx, (unsigned)(planes - p0 < 65535 ? planes - p0 : 65535));
+        if (dtype == VO_F16)
+            instnorm_apply_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, (const __half*)skip, stats, hw, eps, relu, p0);
+        else
+            instnorm_apply_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, stats, hw, eps, relu, p0);
+        VO_CHECK_LAUNCH("vo_instance_norm_apply");
+    }
     return VO_OK;
 }
 
@@ -317,15 +319,17 @@ extern "C" int vo_channel_affine_relu(void* x, const float* scale, const float* 
     VO_REQUIRE(batch > 0 && C > 0 && hw > 0, "vo_channel_affine_relu: bad sizes");
     if (int rc = check_dtype("vo_channel_affine_relu", dtype)) return rc;
     const int64_t planes = batch * C;
-    if (planes > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_channel_affine_relu: batch*C=%lld exceeds 65535", (long long)planes);
     int64_t bx = vo_ceil_div(vo_ceil_div(hw, 4), 256);
     if (bx > 64) bx = 64;
-    const dim3 grid((unsigned)bx, (unsigned)planes);
-    if (dtype == VO_F16)
-        affine_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, scale, shift, (const __half*)skip, C, hw, relu);
-    else
-        affine_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, scale, shift, (const float*)skip, C, hw, relu);
-    VO_CHECK_LAUNCH("vo_channel_affine_relu");
+    // planes ride on grid.y, which holds at most 65535: larger tensors go out in slices
+    for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+        const dim3 grid((unsigned)bx, (unsigned)(planes - p0 < 65535 ? planes - p0 : 65535));
+        if (dtype == VO_F16)
+            affine_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, scale, shift, (const __half*)skip, C, hw, relu, p0);
+        else
+            affine_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, scale, shift, (const float*)skip, C, hw, relu, p0);
+        VO_CHECK_LAUNCH("vo_channel_affine_relu");
+    }
     return VO_OK;
 }
 
@@ -350,10 +354,10 @@ namespace {
 // the second half of a 3x3 convolution with very few output channels, whose first half is
 // a 1x1 convolution with 9K output channels (one plane per filter tap).  One lane per pixel.
 __global__ __launch_bounds__(256) void shift_add_kernel(const float* __restrict__ P, const float* __restrict__ bias,
-                                                        float* __restrict__ out, int K, int H, int W) {
+                                                        float* __restrict__ out, int K, int H, int W, int z0) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    const int n = blockIdx.z / K, k = blockIdx.z % K;
+    const int n = (z0 + blockIdx.z) / K, k = (z0 + blockIdx.z) % K;
     if (x >= W) return;
     const float* p = P + ((int64_t)n * K + k) * 9 * H * W;
     float acc = bias ? bias[k] : 0.0f;
@@ -376,9 +380,13 @@ extern "C" int vo_shift_add_3x3(const float* planes, const float* bias, float* o
                                 void* stream) {
     VO_REQUIRE(planes && out, "vo_shift_add_3x3: null pointer");
     VO_REQUIRE(N > 0 && K > 0 && H > 0 && W > 0, "vo_shift_add_3x3: bad sizes");
-    if (H > 65535 || (int64_t)N * K > 65535) return vo_fail(VO_ERR_UNSUPPORTED, "vo_shift_add_3x3: grid too large");
-    const dim3 grid((unsigned)vo_ceil_div(W, 256), (unsigned)H, (unsigned)(N * K));
-    shift_add_kernel<<<grid, dim3(256), 0, vo_stream(stream)>>>(planes, bias, out, K, H, W);
-    VO_CHECK_LAUNCH("vo_shift_add_3x3");
+    if (H > 65535 || (int64_t)N * K > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_shift_add_3x3: grid too large");
+    // (image, channel) rides on grid.z, which holds at most 65535: larger batches go out in slices
+    for (int64_t z0 = 0; z0 < (int64_t)N * K; z0 += 65535) {
+        const int64_t nz = (int64_t)N * K - z0 < 65535 ? (int64_t)N * K - z0 : 65535;
+        const dim3 grid((unsigned)vo_ceil_div(W, 256), (unsigned)H, (unsigned)nz);
+        shift_add_kernel<<<grid, dim3(256), 0, vo_stream(stream)>>>(planes, bias, out, K, H, W, (int)z0);
+        VO_CHECK_LAUNCH("vo_shift_add_3x3");
+    }
     return VO_OK;
 }

@@ -367,13 +367,13 @@ def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
         if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
             w = weight_for(conv, x)
             U = _winograd_filter_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
-            if U is not None and x.shape[0] * w.shape[0] <= 65535:
+            if U is not None:
                 # the convolution's store accumulates the plane statistics: the norm is one pass
                 stats = torch.zeros((x.shape[0], w.shape[0], 2), device=x.device, dtype=torch.float64)
                 y = ops.conv3x3_winograd(x, U, w.shape[0], stats=stats)
                 return ops.instance_norm_apply_(y, stats, norm.eps, relu, skip)
             Us = _split_s2_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
-            if Us is not None and x.shape[0] * w.shape[0] <= 65535:
+            if Us is not None:
                 # the downsampling layers too leave their plane statistics
                 stats = torch.zeros((x.shape[0], w.shape[0], 2), device=x.device, dtype=torch.float64)
                 y = ops.conv3x3s2_split(x, Us, w.shape[0], stats=stats)
@@ -495,7 +495,7 @@ class ResidualBlock(nn.Module):
             return None
         c1, c2 = self.conv1, self.conv2
         U1 = _winograd_filter_for(x, c1.weight, c1.stride, c1.padding, c1.dilation, c1.groups)
-        if U1 is None or c2.in_channels > 256 or x.shape[0] * max(c1.out_channels, c2.out_channels) > 65535:
+        if U1 is None or c2.in_channels > 256:
             return None
         st1 = torch.zeros((x.shape[0], c1.out_channels, 2), device=x.device, dtype=torch.float64)
         y1 = ops.conv3x3_winograd(x, U1, c1.out_channels, stats=st1)
