@@ -97,8 +97,11 @@ int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, int64_t hw,
                           int dtype, void* stream);
 /* The same normalisation with the plane statistics already known (stats (planes,2) float64:
  * sum, sum of squares, as vo_conv3x3_winograd accumulates them): one read-modify-write pass. */
-int vo_instance_norm_apply(void* x, const void* skip, const double* stats, int64_t planes, int64_t hw,
-                           float eps, int relu, int dtype, void* stream);
+/* With skip_stats (planes,2) the residual branch `skip` is itself a raw convolution output: it is normalised
+ * with its own sums and skip_eps (and rectified when skip_relu != 0) while it is read, i.e.
+ * x = max(act_s(norm(skip)) + act(norm(x)), 0) -- the stems' and the projection shortcuts' norms cost no pass. */
+int vo_instance_norm_apply(void* x, const void* skip, const double* stats, const double* skip_stats, int64_t planes,
+                           int64_t hw, float eps, float skip_eps, int relu, int skip_relu, int dtype, void* stream);
 int vo_channel_affine_relu(void* x, const float* scale, const float* shift, const void* skip,
                            int64_t batch, int C, int64_t hw, int relu, int dtype, void* stream);
 int vo_add_relu(void* a, const void* b, int64_t n, int dtype, void* stream);
@@ -184,6 +187,24 @@ int vo_conv5_bf16x3(const float* x, const void* arranged, float* y, int64_t y_ba
 int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
                         int N, int C, int H, int W, int K, void* stream);
+/* The 1x1 stride-2 convolution of the residual stages' projection shortcuts on the same template (it reads
+ * only the rows the stride lands on): weights (K,C) from vo_conv1x1_bf16x3_filter (ceil(K/64)*64 * C * 4 bytes),
+ * epilogue or stats as vo_conv3x3s2_bf16x3. */
+int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y,
+                        const float* scale, const float* shift, int relu, double* stats,
+                        int N, int C, int H, int W, int K, void* stream);
+/* 7x7 padding-3 convolution (stride 1 or 2) of a ONE- or TWO-channel input in the same arithmetic: the encoders'
+ * stems on a gray frame (the wrappers' three equal channels folded into one, flow/flow_map_RAFT.py:96,101-102)
+ * and the motion encoders' flow branch.  Bound by the store of its output: a workgroup walks four output rows
+ * end to end, so stats (N,K,2) float64 (plane sums of the raw output, for the instance norm that follows the
+ * stem) cost one pair of atomics per channel and four rows.
+ *   vo_conv7x7_bf16x3_filter  weight (K,C,7,7) -> ceil(K/64)*64 * C * 64 * 4 bytes in operand order.
+ *   vo_conv7x7_bf16x3         x (N,C,H,W) -> y (N,K,Ho,Wo), Ho = (H-1)/stride + 1; epilogue v*scale[k] + shift[k]
+ *                             (either may be NULL), ReLU -- or stats, then no epilogue. */
+int vo_conv7x7_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv7x7_bf16x3(const float* x, const void* arranged, float* y, const float* scale, const float* shift, int relu,
+                      double* stats, int N, int C, int H, int W, int K, int stride, void* stream);
 
 /* 1x5 (padding (0,2)) and 5x1 (padding (2,0)) stride-1 float32 convolutions, NCHW, no bias, as
  * one-dimensional Winograd F(4,5) on the matrix cores: the gate convolutions of the separable

@@ -798,6 +798,116 @@ def test_split_bf16_conv3x3s2_matches_the_stock_convolution(vo, N, C, H, W, K):
         assert (got - torch.relu(Fn.instance_norm(want.float(), eps=1e-5))).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 1, 5, 7, 64), (2, 2, 33, 70, 40), (2, 1, 9, 130, 96), (1, 1, 2, 3, 8),
+                                       (2, 1, 96, 128, 64), (1, 2, 60, 80, 128), (3, 1, 61, 191, 64)])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_split_bf16_conv7x7_matches_the_stock_convolution(vo, N, C, H, W, K, stride):
+    """The one- and two-channel 7x7 kernel (stems on a gray frame, the motion encoders' flow branch) against
+    the float64 stock convolution: rows not a multiple of four, widths not a multiple of 64, partial
+    channel blocks, the fused scale / shift / ReLU, and the plane statistics a workgroup accumulates over
+    whole rows."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=130).to(DEV)
+    w = (_rand(K, C, 7, 7, seed=131) / (7 * C ** 0.5)).to(DEV)
+    A = ops.conv7x7_split_filter(w)
+    got = ops.conv7x7_split(x, A, K, stride=stride)
+    want = Fn.conv2d(x.double(), w.double(), None, stride, 3)
+    assert got.shape == want.shape
+    tol = SPLIT_TOL * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() < tol
+    assert torch.equal(got, ops.conv7x7_split(x, A, K, stride=stride))
+    scale, shift = _rand(K, seed=132).to(DEV), _rand(K, seed=133).to(DEV)
+    got = ops.conv7x7_split(x, A, K, scale, shift, True, stride)
+    ref = torch.relu(want.float() * scale[None, :, None, None] + shift[None, :, None, None])
+    assert (got - ref).abs().max().item() < 2 * tol
+    got = ops.conv7x7_split(x, A, K, None, shift, False, stride)
+    assert (got - (want.float() + shift[None, :, None, None])).abs().max().item() < 2 * tol
+    stats = torch.zeros((N, K, 2), device=DEV, dtype=torch.float64)
+    raw = ops.conv7x7_split(x, A, K, stride=stride, stats=stats)
+    want_stats = torch.stack([want.sum((2, 3)), (want * want).sum((2, 3))], dim=2)
+    assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
+    if want.shape[2] * want.shape[3] > 1:
+        got = ops.instance_norm_apply_(raw, stats, 1e-5, True)
+        assert (got - torch.relu(Fn.instance_norm(want.float(), eps=1e-5))).abs().max().item() < 5e-5
+    with pytest.raises(ValueError):
+        ops.conv7x7_split_filter(_rand(8, 3, 7, 7, seed=1).to(DEV))
+    with pytest.raises(ValueError):
+        ops.conv7x7_split(x, A, K, stride=stride, stats=stats, relu=True)
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 16, 5, 8, 64), (2, 16, 33, 70, 40), (2, 64, 9, 132, 100), (1, 16, 1, 2, 3),
+                                       (2, 64, 60, 80, 96), (1, 96, 61, 62, 128)])
+def test_split_bf16_conv1x1s2_matches_the_stock_convolution(vo, N, C, H, W, K):
+    """The projection shortcuts' 1x1 stride-2 convolution on the split-bf16 template (it stages only the rows
+    the stride lands on) against the float64 stock convolution, with epilogue and plane statistics."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=140).to(DEV)
+    w = (_rand(K, C, 1, 1, seed=141) / C ** 0.5).to(DEV)
+    A = ops.conv1x1_split_filter(w)
+    got = ops.conv1x1s2_split(x, A, K)
+    want = Fn.conv2d(x.double(), w.double(), None, 2, 0)
+    assert got.shape == want.shape
+    tol = SPLIT_TOL * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() < tol
+    scale, shift = _rand(K, seed=142).to(DEV), _rand(K, seed=143).to(DEV)
+    got = ops.conv1x1s2_split(x, A, K, scale, shift, True)
+    ref = torch.relu(want.float() * scale[None, :, None, None] + shift[None, :, None, None])
+    assert (got - ref).abs().max().item() < 2 * tol
+    stats = torch.zeros((N, K, 2), device=DEV, dtype=torch.float64)
+    ops.conv1x1s2_split(x, A, K, stats=stats)
+    want_stats = torch.stack([want.sum((2, 3)), (want * want).sum((2, 3))], dim=2)
+    assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
+
+
+def test_instance_norm_join_normalises_a_raw_skip_branch(vo):
+    """vo_instance_norm_apply with skip statistics: relu(act(norm(skip)) + relu(norm(x))) from two raw tensors
+    and their plane sums, against the stock operators, with and without the ReLU on the skip branch."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x, s = _rand(2, 5, 13, 18, seed=150).to(DEV) * 3 + 1, _rand(2, 5, 13, 18, seed=151).to(DEV) * 0.5 - 2
+    sums = lambda t: torch.stack([t.double().sum((2, 3)), (t.double() ** 2).sum((2, 3))], dim=2).contiguous()
+    for skip_relu in (True, False):
+        sn = Fn.instance_norm(s, eps=1e-3)
+        want = torch.relu((torch.relu(sn) if skip_relu else sn) + torch.relu(Fn.instance_norm(x, eps=1e-5)))
+        got = ops.instance_norm_apply_(x.clone(), sums(x), 1e-5, True, s, sums(s), 1e-3, skip_relu)
+        assert (got - want).abs().max().item() < 1e-5
+    with pytest.raises(ValueError):
+        ops.instance_norm_apply_(x.clone(), sums(x), 1e-5, True, None, sums(s))
+
+
+def test_encoder_with_deferred_norms_matches_stock_operators(vo):
+    """BasicEncoder (instance norm) on a one-plane gray input: the stem leaves its sums and is never normalised
+    in memory (the first block's convolution and residual join normalise it as they read), the stride-2
+    blocks' shortcuts likewise; against the stock-operator forward of the same module on the replicated
+    three-channel input."""
+    from visual_odometry_amd.raft import layers
+    from visual_odometry_amd.raft.layers import BasicEncoder
+    torch.manual_seed(5)
+    for down in (3, 2):
+        enc = BasicEncoder(output_dim=256, norm_fn="instance", downsample=down).to(DEV).eval()
+        g = (_rand(2, 1, 192, 256, seed=160) * 0.5).to(DEV)
+        with torch.no_grad():
+            x3 = g.expand(-1, 3, -1, -1).contiguous()
+            want = enc.conv2(enc.layer3(enc.layer2(enc.layer1(torch.relu(enc.norm1(enc.conv1(x3)))))))
+            with layers.fused_passes():
+                rec = {}
+                old = ops_recorder(rec)
+                try:
+                    got = enc(g)
+                finally:
+                    ops_recorder(old)
+        assert "vo_instance_norm_relu" not in rec                   # no stand-alone statistics pass left
+        assert "vo_conv7x7_bf16x3" in rec and "vo_conv1x1s2_bf16x3" in rec
+        assert (got - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item())
+
+
+def ops_recorder(rec):
+    from visual_odometry_amd import ops
+    return ops.set_recorder(rec)
+
+
 def test_networks_agree_across_conv_arithmetic(vo):
     """Flow and disparity at 480x640 (every 3x3 layer large enough for the split-bf16 kernel) with the
     float32-matrix-instruction kernels only against the default split-bf16 products, and each against

@@ -22,7 +22,7 @@ SIGNATURES = {
     "vo_remap_bilinear_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_erode3x3_u8": [_P, _P, _I, _I, _P],
     "vo_instance_norm_relu": [_P, _P, _L, _L, _F, _I, _I, _P],
-    "vo_instance_norm_apply": [_P, _P, _P, _L, _L, _F, _I, _I, _P],
+    "vo_instance_norm_apply": [_P, _P, _P, _P, _L, _L, _F, _F, _I, _I, _I, _P],
     "vo_channel_affine_relu": [_P, _P, _P, _P, _L, _I, _L, _I, _I, _P],
     "vo_add_relu": [_P, _P, _L, _I, _P],
     "vo_resize_bilinear": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -36,6 +36,10 @@ SIGNATURES = {
     "vo_conv5_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv5_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv3x3s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "vo_conv1x1_bf16x3_filter": [_P, _P, _I, _I, _P],
+    "vo_conv1x1s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "vo_conv7x7_bf16x3_filter": [_P, _P, _I, _I, _P],
+    "vo_conv7x7_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_winograd1d_filter": [_P, _P, _I, _I, _P],
     "vo_conv5_winograd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_filter": [_P, _P, _I, _I, _P],

@@ -52,7 +52,8 @@ struct Geo {
     static constexpr int TH = 4 * NTW;
     static constexpr int PAD_H = R / 2, PAD_W = S / 2;
     static constexpr int SLACK = PAD_W & 1;                                   // the patch starts at an even input column
-    static constexpr int PR = (TH - 1) * ST + R;                              // patch rows
+    static constexpr int RS = R == 1 ? ST : 1;                                // input rows between patch rows (a one-row filter skips the rows a stride passes over)
+    static constexpr int PR = ((TH - 1) * ST + R - 1) / RS + 1;               // patch rows
     static constexpr int PC = ((TW - 1) * ST + S + SLACK + 1) / 2 * 2;        // patch columns (even)
     static constexpr int PLANE = PR * PC * 16;                                // bytes of one (part, k-half) plane
     static constexpr int UNITS = 2 * PR * (PC / 2);                           // staging units: (k-half, row, column pair)
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     for (int i = 0; i < ROUNDS; ++i) {
         const int u = tid + i * NT;
         const int kg = u / (PR * (PC / 2)), rem = u - kg * (PR * (PC / 2)), row = rem / (PC / 2), pr = rem - row * (PC / 2);
-        const int gy = y0 * G::ST - G::PAD_H + row, gx = x0 * G::ST - G::PAD_W - G::SLACK + 2 * pr;
+        const int gy = y0 * G::ST - G::PAD_H + row * G::RS, gx = x0 * G::ST - G::PAD_W - G::SLACK + 2 * pr;
         const bool ok = u < UNITS && gy >= 0 && gy < H && gx >= 0 && gx < W;
         u_off[i] = ok ? ((kg * 8 * H + gy) * W + gx) * 4 : (int)0x80000000;
         // stride 1: the pair's pixels lie side by side; stride 2: the even one in the row's first half, the odd one in its second
@@ -213,14 +214,14 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     // A fragment of (tap, part, mt): weights area + ((tap*2 + part)*2 + mt) KiB + 16*lane
     // B fragment of (tap r, s), pixel tile nt: patch row (NTW*wave + nt)*stride + r, patch column (lane & 31)*stride + s + slack
     const unsigned char* a_lds = lds + 4 * PLANE + lane * 16;
-    const unsigned char* b_lds = lds + (lane >> 5) * PLANE + ((NTW * wave * G::ST) * PC + (lane & 31)) * 16;
+    const unsigned char* b_lds = lds + (lane >> 5) * PLANE + ((NTW * wave * G::ST / G::RS) * PC + (lane & 31)) * 16;
     auto read_a = [&](int tap, int part, int mt) {
         return *reinterpret_cast<const bf16x8*>(a_lds + ((tap * 2 + part) * 2 + mt) * 1024);
     };
     auto read_b = [&](int tap, int nt, int part) {
         const int r = tap / G::S, c = tap % G::S + G::SLACK;                 // lane n reads patch column n*stride + c
         const int pos = G::ST == 1 ? c : (c & 1) * (PC / 2) + (c >> 1);
-        return *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PLANE + ((nt * G::ST + r) * PC + pos) * 16);
+        return *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PLANE + (((nt * G::ST + r) / G::RS) * PC + pos) * 16);
     };
 
     // a chunk's weights are a linear copy (they are stored in operand order); they are requested at the
@@ -504,6 +505,7 @@ using Geo3x3 = Geo<3, 3, 1, 4>;
 using Geo1x5 = Geo<1, 5, 1, 4>;
 using Geo5x1 = Geo<5, 1, 1, 4>;
 using Geo3x3s2 = Geo<3, 3, 2, 1>;
+using Geo1x1s2 = Geo<1, 1, 2, 1>;
 
 }  // namespace
 
@@ -534,5 +536,15 @@ extern "C" int vo_conv5_bf16x3(const float* x, const void* arranged, float* y, i
 extern "C" int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y, const float* scale, const float* shift,
                                    int relu, double* stats, int N, int C, int H, int W, int K, void* stream) {
     return launch_conv<Geo3x3s2>("vo_conv3x3s2_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, stats, nullptr, 0.0f, N, C,
+                                 H, W, K, vo_stream(stream));
+}
+
+extern "C" int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream) {
+    return split_filter("vo_conv1x1_bf16x3_filter", weight, arranged, K, C, 1, vo_stream(stream));
+}
+
+extern "C" int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y, const float* scale, const float* shift,
+                                   int relu, double* stats, int N, int C, int H, int W, int K, void* stream) {
+    return launch_conv<Geo1x1s2>("vo_conv1x1s2_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, stats, nullptr, 0.0f, N, C,
                                  H, W, K, vo_stream(stream));
 }

@@ -75,16 +75,27 @@ __global__ __launch_bounds__(256) void instnorm_kernel(T* __restrict__ x, const 
     }
 }
 
-// Instance norm with known statistics: grid.y = plane, grid.x strides the plane.
+// Instance norm with known statistics: grid.y = plane, grid.x strides the plane.  With ``skip_stats`` the
+// residual branch too is a raw convolution output with its plane sums: it is normalised (and, with
+// ``skip_relu``, rectified) on the fly, so the branch never exists in normalised form.
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(T* __restrict__ x, const T* __restrict__ skip,
-                                                             const double* __restrict__ stats, int64_t hw, float eps,
-                                                             int relu, int64_t plane0) {
+                                                             const double* __restrict__ stats,
+                                                             const double* __restrict__ skip_stats, int64_t hw, float eps,
+                                                             float skip_eps, int relu, int skip_relu, int64_t plane0) {
     const int64_t plane = plane0 + blockIdx.y;
     const double mean = stats[2 * plane] / (double)hw;
     double var = stats[2 * plane + 1] / (double)hw - mean * mean;
     if (var < 0.0) var = 0.0;
     const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    float sm = 0.0f, sr = 1.0f;
+    if (skip_stats) {
+        const double smean = skip_stats[2 * plane] / (double)hw;
+        double svar = skip_stats[2 * plane + 1] / (double)hw - smean * smean;
+        if (svar < 0.0) svar = 0.0;
+        sm = (float)smean; sr = (float)(1.0 / sqrt(svar + (double)skip_eps));
+    }
+    const float slo = skip_relu ? 0.0f : -INFINITY;
     T* p = x + plane * hw;
     const T* q = skip ? skip + plane * hw : nullptr;
     const int64_t n4 = aligned4<T>(p, q) ? (hw >> 2) : 0;
@@ -94,13 +105,24 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(T* __restrict__ x, 
         float4 v = vo_ld4<T>(p, i);
         v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
         if (relu) v = relu4(v);
-        if (q) v = relu4(add4(v, vo_ld4<T>(q, i)));
+        if (q) {
+            float4 s = vo_ld4<T>(q, i);
+            if (skip_stats) {
+                s.x = fmaxf((s.x - sm) * sr, slo); s.y = fmaxf((s.y - sm) * sr, slo);
+                s.z = fmaxf((s.z - sm) * sr, slo); s.w = fmaxf((s.w - sm) * sr, slo);
+            }
+            v = relu4(add4(v, s));
+        }
         vo_st4<T>(p, i, v);
     }
     for (int64_t i = (n4 << 2) + t; i < hw; i += stride) {
         float v = (vo_ld1(p, i) - m) * r;
         if (relu) v = fmaxf(v, 0.0f);
-        if (q) v = fmaxf(v + vo_ld1(q, i), 0.0f);
+        if (q) {
+            float s = vo_ld1(q, i);
+            if (skip_stats) s = fmaxf((s - sm) * sr, slo);
+            v = fmaxf(v + s, 0.0f);
+        }
         vo_st1(p, i, v);
     }
 }
@@ -294,10 +316,12 @@ extern "C" int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, 
     return VO_OK;
 }
 
-extern "C" int vo_instance_norm_apply(void* x, const void* skip, const double* stats, int64_t planes, int64_t hw,
-                                      float eps, int relu, int dtype, void* stream) {
+extern "C" int vo_instance_norm_apply(void* x, const void* skip, const double* stats, const double* skip_stats, int64_t planes,
+                                      int64_t hw, float eps, float skip_eps, int relu, int skip_relu, int dtype, void* stream) {
     VO_REQUIRE(x && stats, "vo_instance_norm_apply: null pointer");
     VO_REQUIRE(planes > 0 && hw > 0, "vo_instance_norm_apply: bad sizes");
+    VO_REQUIRE(!(skip_stats && !skip), "vo_instance_norm_apply: skip statistics without a skip tensor");
+    VO_REQUIRE(skip != x, "vo_instance_norm_apply: skip must not alias the tensor normalised in place");
     if (int rc = check_dtype("vo_instance_norm_apply", dtype)) return rc;
     int64_t bx = vo_ceil_div(vo_ceil_div(hw, 4), 256);
     if (bx > 64) bx = 64;
@@ -305,9 +329,11 @@ extern "C" int vo_instance_norm_apply(void* x, const void* skip, const double* s
     for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
         const dim3 grid((unsigned)bx, (unsigned)(planes - p0 < 65535 ? planes - p0 : 65535));
         if (dtype == VO_F16)
-            instnorm_apply_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, (const __half*)skip, stats, hw, eps, relu, p0);
+            instnorm_apply_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, (const __half*)skip, stats, skip_stats, hw,
+                                                                                  eps, skip_eps, relu, skip_relu, p0);
         else
-            instnorm_apply_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, stats, hw, eps, relu, p0);
+            instnorm_apply_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, stats, skip_stats, hw,
+                                                                                 eps, skip_eps, relu, skip_relu, p0);
         VO_CHECK_LAUNCH("vo_instance_norm_apply");
     }
     return VO_OK;

@@ -153,15 +153,21 @@ def instance_norm_relu_(x: torch.Tensor, eps: float = 1e-5, relu: bool = True, s
 
 
 def instance_norm_apply_(x: torch.Tensor, stats: torch.Tensor, eps: float = 1e-5, relu: bool = True,
-                         skip: torch.Tensor | None = None) -> torch.Tensor:
+                         skip: torch.Tensor | None = None, skip_stats: torch.Tensor | None = None,
+                         skip_eps: float = 1e-5, skip_relu: bool = False) -> torch.Tensor:
     """instance_norm_relu_ with the plane statistics (N,C,2) float64 (sum, sum of squares)
-    already accumulated by the producing convolution: a single read-modify-write pass."""
+    already accumulated by the producing convolution: a single read-modify-write pass.  With
+    ``skip_stats`` the residual branch is a raw convolution output too and is normalised (and rectified
+    with ``skip_relu``) while it is read: x = relu(act_s(norm(skip)) + act(norm(x)))."""
     N, C, H, W = x.shape
     if stats.numel() != N * C * 2:
         raise ValueError("stats must be (N,C,2)")
+    if skip_stats is not None and (skip is None or skip_stats.numel() != N * C * 2):
+        raise ValueError("skip_stats must be (N,C,2) and come with a skip tensor")
     px, dt, es = _act(x, "x")
-    _call("vo_instance_norm_apply", px, _skip_ptr(skip, x), _dev(stats, "stats", torch.float64), N * C, H * W, float(eps),
-          int(relu), dt, _stream(), nbytes=(2 + (skip is not None)) * es * x.numel())
+    _call("vo_instance_norm_apply", px, _skip_ptr(skip, x), _dev(stats, "stats", torch.float64),
+          _opt(skip_stats, "skip_stats", torch.float64), N * C, H * W, float(eps), float(skip_eps), int(relu),
+          int(skip_relu), dt, _stream(), nbytes=(2 + (skip is not None)) * es * x.numel())
     return x
 
 
@@ -380,6 +386,81 @@ def conv3x3s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torc
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
           _opt(stats, "stats", torch.float64), N, C, H, W, K, _stream(),
           nbytes=4 * (x.numel() + out.numel()), flops=2 * 27 * N * K * C * Ho * Wo)
+    return out
+
+
+def conv1x1_split_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,1,1) or (K,C) float32 weight, C a multiple of 16 -> the bf16 high/low parts in operand order
+    that conv1x1s2_split consumes (a float32 tensor used as raw storage, ceil(K/64)*64*C elements)."""
+    if weight.dim() not in (2, 4) or (weight.dim() == 4 and tuple(weight.shape[2:]) != (1, 1)):
+        raise ValueError("weight must be (K,C,1,1) or (K,C)")
+    K, C = weight.shape[:2]
+    if C % 16:
+        raise ValueError("the split-bf16 path needs a multiple of 16 input channels")
+    out = torch.empty(((K + 63) // 64 * 64 * C,), device=weight.device, dtype=torch.float32)
+    _call("vo_conv1x1_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C,
+          _stream())
+    return out
+
+
+def conv1x1s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+                    shift: torch.Tensor | None = None, relu: bool = False, stats: torch.Tensor | None = None) -> torch.Tensor:
+    """conv2d(x, weight(K,C,1,1), stride=2) on the split-bf16 direct kernel (weights from
+    conv1x1_split_filter), optional epilogue, or ``stats`` (zeroed float64 (N,K,2)) receiving the plane
+    sums of the raw output."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C:
+        raise ValueError("arranged weights do not match (K, C)")
+    if W % 2:
+        raise ValueError("the split-bf16 kernel needs an even width")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    if stats is not None and (stats.numel() != N * K * 2 or shift is not None or relu):
+        raise ValueError("stats must be (N,K,2) float64 and excludes the epilogue")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
+    _call("vo_conv1x1s2_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
+          _opt(stats, "stats", torch.float64), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() // 2 + out.numel()), flops=2 * 3 * N * K * C * Ho * Wo)
+    return out
+
+
+def conv7x7_split_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,C,7,7) float32 weight, C = 1 or 2 -> the bf16 high/low parts in operand order that conv7x7_split
+    consumes (a float32 tensor used as raw storage, ceil(K/64)*64*C*64 elements)."""
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (7, 7) or weight.shape[1] not in (1, 2):
+        raise ValueError("weight must be (K,C,7,7) with one or two input channels")
+    K, C = weight.shape[:2]
+    out = torch.empty(((K + 63) // 64 * 64 * C * 64,), device=weight.device, dtype=torch.float32)
+    _call("vo_conv7x7_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C,
+          _stream())
+    return out
+
+
+def conv7x7_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+                  shift: torch.Tensor | None = None, relu: bool = False, stride: int = 1,
+                  stats: torch.Tensor | None = None) -> torch.Tensor:
+    """x (N,C,H,W) float32, C = 1 or 2 -> conv2d(x, weight, stride=stride, padding=3) with split-bf16 products,
+    then [* scale[k] + shift[k]] [ReLU], or ``stats`` (zeroed float64 (N,K,2)) receiving the plane sums of the
+    raw output."""
+    N, C, H, W = x.shape
+    if stride not in (1, 2):
+        raise ValueError("stride must be 1 or 2")
+    if C not in (1, 2) or arranged.numel() != (K + 63) // 64 * 64 * C * 64:
+        raise ValueError("arranged weights do not match (K, C), C = 1 or 2")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    if stats is not None and (stats.numel() != N * K * 2 or shift is not None or relu):
+        raise ValueError("stats must be (N,K,2) float64 and excludes the epilogue")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
+    _call("vo_conv7x7_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
+          _opt(stats, "stats", torch.float64), N, C, H, W, K, stride, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * 3 * N * K * C * 64 * Ho * Wo)
     return out
 
 

@@ -214,6 +214,42 @@ def _conv7x7_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
     return cached[1]
 
 
+def _conv7x7_split_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
+    """The cached split-bf16 weights when this convolution can run on the split-bf16 7x7 kernel (7x7 / stride 1
+    or 2 / padding 3, one or two input channels, output channels a multiple of 8, float32), else None."""
+    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+            and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (7, 7) and tuple(stride) in ((1, 1), (2, 2))
+            and tuple(padding) == (3, 3) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
+            and x.shape[1] in (1, 2) and weight.shape[0] % 8 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30
+            and weight.shape[0] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
+        return None
+    key = (weight._version, weight.data_ptr())
+    cached = getattr(weight, "_vo_conv7x7_split", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.conv7x7_split_filter(weight))
+        weight._vo_conv7x7_split = cached
+    return cached[1]
+
+
+def _conv1x1s2_split_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
+    """The cached split-bf16 weights when this 1x1 stride-2 convolution (a residual stage's projection
+    shortcut) can run on the split-bf16 direct kernel, else None."""
+    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+            and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (1, 1) and tuple(stride) == (2, 2)
+            and tuple(padding) == (0, 0) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
+            and x.shape[1] % 16 == 0 and x.shape[3] % 2 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
+        return None
+    wo = (x.shape[3] - 1) // 2 + 1
+    if wo < 0.6 * ((wo + 31) // 32 * 32):
+        return None
+    key = (weight._version, weight.data_ptr())
+    cached = getattr(weight, "_vo_conv1x1s2_split", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.conv1x1_split_filter(weight))
+        weight._vo_conv1x1s2_split = cached
+    return cached[1]
+
+
 def _conv3x3s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached arranged weights when this convolution can run on the streaming 3x3 stride-2
     matrix-core kernel (float32, input channels a multiple of 8, an output width that fills the
@@ -267,6 +303,9 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     Wg = _conv1x1_weights_for(x, weight, stride, padding, dilation, groups)
     if Wg is not None:
         return ops.conv1x1(x, Wg, weight.shape[0])
+    W7 = _conv7x7_split_weights_for(x, weight, stride, padding, dilation, groups)
+    if W7 is not None:
+        return ops.conv7x7_split(x, W7, weight.shape[0], stride=tuple(stride)[0])
     Wg = _conv7x7_weights_for(x, weight, stride, padding, dilation, groups)
     if Wg is not None:
         return ops.conv7x7(x, Wg, weight.shape[0], stride=tuple(stride)[0])
@@ -313,6 +352,9 @@ def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor
         if Wg is not None:
             return ops.conv1x1(x, Wg, w.shape[0], scale, shift, relu, out)
         if out is None:
+            W7 = _conv7x7_split_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if W7 is not None:
+                return ops.conv7x7_split(x, W7, w.shape[0], scale, shift, relu, conv.stride[0])
             Wg = _conv7x7_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv7x7(x, Wg, w.shape[0], scale, shift, relu, conv.stride[0])
@@ -340,6 +382,9 @@ def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
         # a strided 1x1 convolution only ever reads the sampled pixels: gather them once and
         # run a dense GEMM instead of MIOpen's strided 1x1 path (18 TFLOP/s on these shapes)
         w = weight_for(conv, x)
+        Ws = _conv1x1s2_split_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if Ws is not None:
+            return ops.conv1x1s2_split(x, Ws, w.shape[0])
         if (_WINOGRAD and conv.stride == (2, 2) and x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_cuda
                 and x.is_contiguous() and x.shape[1] % 8 == 0 and conv.groups == 1 and conv.dilation == (1, 1)
                 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
@@ -356,16 +401,42 @@ def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     return conv2d_nobias(x, weight_for(conv, x), conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+class RawNorm:
+    """act(instance_norm(y)) that has not been written out: the raw convolution output ``y`` with its plane
+    sums ``stats`` (N,C,2).  Consumers that can normalise while they read (the split-bf16 3x3 kernel's load,
+    the residual join's skip branch) take it as it is; ``tensor()`` materialises it in place otherwise."""
+
+    def __init__(self, y: torch.Tensor, stats: torch.Tensor, eps: float, relu: bool):
+        self.y, self.stats, self.eps, self.relu = y, stats, eps, relu
+        self.shape, self.dtype, self.device = y.shape, y.dtype, y.device
+
+    def tensor(self) -> torch.Tensor:
+        return ops.instance_norm_apply_(self.y, self.stats, self.eps, self.relu)
+
+
 def conv_norm_act(x: torch.Tensor, conv: nn.Conv2d, norm: nn.Module, relu: bool,
-                  skip: torch.Tensor | None = None) -> torch.Tensor:
+                  skip: torch.Tensor | None = None, lazy: bool = False):
     """relu(norm(conv(x))) (or without the ReLU); with ``skip`` the residual join
     relu(skip + .) on top of it.  Fused path: the convolution runs WITHOUT its bias and
     one in-place HIP pass applies bias + norm + ReLU (+ join) -- instance norm removes
     any per-channel constant, so the bias drops out entirely; inference batch norm
-    absorbs it into its shift.  Stock operators otherwise."""
+    absorbs it into its shift.  Stock operators otherwise.  ``lazy``: when the convolution
+    leaves its plane sums, return a RawNorm (the normalisation left to the consumer)."""
     if _fusable(x) and (skip is None or (skip.is_cuda and skip.dtype == x.dtype and skip.is_contiguous())):
         if isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats:
             w = weight_for(conv, x)
+            y = None
+            if x.dtype == torch.float32:
+                W7 = _conv7x7_split_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+                Ws = _conv1x1s2_split_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+                if W7 is not None or Ws is not None:
+                    # the stems and the projection shortcuts too leave their plane statistics
+                    stats = torch.zeros((x.shape[0], w.shape[0], 2), device=x.device, dtype=torch.float64)
+                    y = (ops.conv7x7_split(x, W7, w.shape[0], stride=conv.stride[0], stats=stats) if W7 is not None
+                         else ops.conv1x1s2_split(x, Ws, w.shape[0], stats=stats))
+                    if lazy and skip is None:
+                        return RawNorm(y, stats, norm.eps, relu)
+                    return ops.instance_norm_apply_(y, stats, norm.eps, relu, skip)
             U = _winograd_filter_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
             if U is not None:
                 # the convolution's store accumulates the plane statistics: the norm is one pass
@@ -476,36 +547,65 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
+        """x: a tensor, or a RawNorm (the stem's output still waiting for its normalisation)."""
         chained = self._instance_norm_chain(x)
         if chained is not None:
             return chained
+        if isinstance(x, RawNorm):
+            x = x.tensor()
         y = conv_norm_act(x, self.conv1, self.norm1, True)
         if self.downsample is not None:
             x = conv_norm_act(x, self.downsample[0], self.norm3, False)
         return conv_norm_act(y, self.conv2, self.norm2, True, skip=x)        # relu(x + relu(norm2(conv2(y))))
 
     def _instance_norm_chain(self, x):
-        """Both convolutions on the Winograd kernel with instance norm: conv1's store leaves
+        """Both 3x3 convolutions on the matrix-core kernels with instance norm: conv1's store leaves
         the plane sums of its raw output, conv2 normalises + ReLUs that output while loading
         it and leaves its own sums, and one pass applies norm2 + ReLU + the residual join.
-        The normalised tensor between the two convolutions is never written."""
+        The normalised tensor between the two convolutions is never written.  The same holds for the
+        block's input when it arrives as a RawNorm (conv1 and the join normalise it as they read) and for a
+        projection shortcut (its 1x1 stride-2 convolution leaves its sums, the join normalises it)."""
         plain = lambda n: isinstance(n, nn.InstanceNorm2d) and not n.affine and not n.track_running_stats
-        if not (_fusable(x) and x.dtype == torch.float32 and self.downsample is None and plain(self.norm1)
-                and plain(self.norm2)):
+        raw = x if isinstance(x, RawNorm) else None
+        xt = raw.y if raw is not None else x
+        if not (_fusable(xt) and xt.dtype == torch.float32 and plain(self.norm1) and plain(self.norm2)):
             return None
         c1, c2 = self.conv1, self.conv2
-        U1 = _winograd_filter_for(x, c1.weight, c1.stride, c1.padding, c1.dilation, c1.groups)
-        if U1 is None or c2.in_channels > 256:
+        if c2.in_channels > 256 or (raw is not None and (not raw.relu or c1.in_channels > 256)):
             return None
-        st1 = torch.zeros((x.shape[0], c1.out_channels, 2), device=x.device, dtype=torch.float64)
-        y1 = ops.conv3x3_winograd(x, U1, c1.out_channels, stats=st1)
+        st1 = torch.zeros((xt.shape[0], c1.out_channels, 2), device=xt.device, dtype=torch.float64)
+        if self.downsample is None:
+            U1 = _winograd_filter_for(xt, c1.weight, c1.stride, c1.padding, c1.dilation, c1.groups)
+            if U1 is None:
+                return None
+            if raw is not None:
+                y1 = ops.conv3x3_winograd(xt, U1, c1.out_channels, stats=st1, in_stats=raw.stats, in_eps=raw.eps)
+            else:
+                y1 = ops.conv3x3_winograd(xt, U1, c1.out_channels, stats=st1)
+            skip, skip_stats = xt, (raw.stats if raw is not None else None)
+            skip_eps, skip_relu = (raw.eps if raw is not None else 1e-5), True
+        else:
+            # stride-2 block: conv1 on the stride-2 kernel, the shortcut's 1x1 stride-2 convolution with its own sums
+            if raw is not None or not plain(self.norm3):
+                return None
+            d = self.downsample[0]
+            Us = _split_s2_weights_for(xt, c1.weight, c1.stride, c1.padding, c1.dilation, c1.groups)
+            Ws = _conv1x1s2_split_weights_for(xt, d.weight, d.stride, d.padding, d.dilation, d.groups)
+            if Us is None or Ws is None:
+                return None
+            y1 = ops.conv3x3s2_split(xt, Us, c1.out_channels, stats=st1)
+            skip_stats = torch.zeros((xt.shape[0], d.out_channels, 2), device=xt.device, dtype=torch.float64)
+            skip = ops.conv1x1s2_split(xt, Ws, d.out_channels, stats=skip_stats)
+            skip_eps, skip_relu = self.norm3.eps, False
         U2 = _winograd_filter_for(y1, c2.weight, c2.stride, c2.padding, c2.dilation, c2.groups)
         if U2 is None:
             y1 = ops.instance_norm_apply_(y1, st1, self.norm1.eps, True)
-            return conv_norm_act(y1, c2, self.norm2, True, skip=x)
-        st2 = torch.zeros((x.shape[0], c2.out_channels, 2), device=x.device, dtype=torch.float64)
+            if skip_stats is not None:
+                skip = ops.instance_norm_apply_(skip, skip_stats, skip_eps, skip_relu)
+            return conv_norm_act(y1, c2, self.norm2, True, skip=skip)
+        st2 = torch.zeros((xt.shape[0], c2.out_channels, 2), device=xt.device, dtype=torch.float64)
         y2 = ops.conv3x3_winograd(y1, U2, c2.out_channels, stats=st2, in_stats=st1, in_eps=self.norm1.eps)
-        return ops.instance_norm_apply_(y2, st2, self.norm2.eps, True, x)
+        return ops.instance_norm_apply_(y2, st2, self.norm2.eps, True, skip, skip_stats, skip_eps, skip_relu)
 
 
 def _init_weights(module: nn.Module):
@@ -546,7 +646,7 @@ class BasicEncoder(nn.Module):
     def forward(self, x: torch.Tensor, pixel_major: bool = False) -> torch.Tensor:
         """``pixel_major``: return float32 (B,H,W,D) instead of (B,D,H,W).  x: three channels, or the
         one plane of a gray frame."""
-        x = conv_norm_act(x, gray_stem(self.conv1, x), self.norm1, True)
+        x = conv_norm_act(x, gray_stem(self.conv1, x), self.norm1, True, lazy=True)     # a RawNorm when the stem leaves its sums
         x = self.layer3(self.layer2(self.layer1(x)))
         return conv_pixel_major(x, self.conv2) if pixel_major else conv_plain(x, self.conv2)
 
