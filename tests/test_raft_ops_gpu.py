@@ -643,12 +643,13 @@ SPLIT_TOL = 2e-5                   # relative to the largest output value (measu
 
 @pytest.mark.parametrize("N,C,H,W,K", [(2, 16, 16, 32, 64), (1, 16, 37, 54, 40), (2, 64, 60, 80, 126), (1, 32, 17, 16, 32),
                                        (3, 128, 33, 46, 192), (1, 16, 1, 2, 33), (2, 96, 30, 40, 96), (1, 48, 70, 100, 72),
-                                       (1, 256, 15, 20, 128), (5, 64, 120, 160, 64)])
+                                       (1, 256, 15, 20, 128), (5, 64, 120, 160, 64), (2, 32, 50, 74, 33), (1, 16, 63, 14, 64)])
 def test_split_bf16_conv3x3_matches_direct_convolution(vo, N, C, H, W, K):
     """The split-bf16 direct 3x3 kernel (each float32 product from three bf16 matrix-core terms, float32
     accumulation) against the float64 direct convolution: ragged image sizes, one-pixel-high and
     two-pixel-wide maps, output channels that do not fill a 64-block (half blocks included), several
-    chunks of input channels, more tiles than workgroup slots, run-to-run identical results.
+    chunks of input channels, more tiles than workgroup slots, maps that take the 32x16 block geometry
+    (60x80, 30x40, 50x74, 63x14) as well as the 16x32 one, run-to-run identical results.
     Tolerance 2e-5 of the largest output, the bar of the float32 F(2x2,3x3) kernel."""
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops
@@ -678,26 +679,26 @@ def test_split_bf16_conv3x3_epilogue_statistics_and_slices(vo):
     import torch.nn.functional as Fn
     from visual_odometry_amd import ops
     from visual_odometry_amd.raft import layers
-    N, C, H, W, K = 2, 32, 21, 28, 40
-    x, w = _rand(N, C, H, W, seed=70).to(DEV), (_rand(K, C, 3, 3, seed=71) / 12).to(DEV)
-    scale, shift, skip = _rand(K, seed=72).to(DEV), _rand(K, seed=73).to(DEV), _rand(N, K, H, W, seed=74).to(DEV)
-    U = ops.conv3x3_split_filter(w)
-    y = Fn.conv2d(x.double(), w.double(), None, 1, 1).float()
     b = lambda v: v[None, :, None, None]
-    cases = [((None, shift, False, None), y + b(shift)), ((None, shift, True, None), torch.relu(y + b(shift))),
-             ((scale, shift, True, None), torch.relu(y * b(scale) + b(shift))),
-             ((scale, shift, True, skip), torch.relu(skip + torch.relu(y * b(scale) + b(shift)))),
-             ((None, None, True, skip), torch.relu(skip + torch.relu(y)))]
-    for args, want in cases:
-        got = ops.conv3x3_winograd(x, U, K, *args)
-        assert (got - want).abs().max().item() < SPLIT_TOL * max(1.0, want.abs().max().item())
+    for (N, C, H, W, K) in [(2, 32, 50, 74, 40), (2, 32, 21, 28, 40)]:      # 32x16 blocks, then 16x32 blocks
+        x, w = _rand(N, C, H, W, seed=70).to(DEV), (_rand(K, C, 3, 3, seed=71) / 12).to(DEV)
+        scale, shift, skip = _rand(K, seed=72).to(DEV), _rand(K, seed=73).to(DEV), _rand(N, K, H, W, seed=74).to(DEV)
+        U = ops.conv3x3_split_filter(w)
+        y = Fn.conv2d(x.double(), w.double(), None, 1, 1).float()
+        cases = [((None, shift, False, None), y + b(shift)), ((None, shift, True, None), torch.relu(y + b(shift))),
+                 ((scale, shift, True, None), torch.relu(y * b(scale) + b(shift))),
+                 ((scale, shift, True, skip), torch.relu(skip + torch.relu(y * b(scale) + b(shift)))),
+                 ((None, None, True, skip), torch.relu(skip + torch.relu(y)))]
+        for args, want in cases:
+            got = ops.conv3x3_winograd(x, U, K, *args)
+            assert (got - want).abs().max().item() < SPLIT_TOL * max(1.0, want.abs().max().item())
     wide = torch.full((N, 7 + K + 5, H, W), 3.25, device=DEV)
     got = ops.conv3x3_winograd(x, U, K, None, shift, True, out=wide[:, 7:7 + K])
     assert got.data_ptr() == wide[:, 7:7 + K].data_ptr()
     assert (wide[:, 7:7 + K] - torch.relu(y + b(shift))).abs().max().item() < SPLIT_TOL * max(1.0, y.abs().max().item())
     assert torch.all(wide[:, :7] == 3.25) and torch.all(wide[:, 7 + K:] == 3.25)
     # statistics of the raw output -> one-pass instance norm (+ ReLU + residual join)
-    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (3, 64, 60, 80, 64), (1, 16, 16, 16, 33), (2, 96, 35, 66, 96)]:
+    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (3, 64, 60, 80, 64), (1, 16, 16, 16, 33), (2, 96, 35, 66, 96), (2, 16, 50, 74, 40)]:
         x, w = _rand(N, C, H, W, seed=90).to(DEV), (_rand(K, C, 3, 3, seed=91) / 12).to(DEV)
         skip = _rand(N, K, H, W, seed=92).to(DEV)
         U = ops.conv3x3_split_filter(w)
@@ -721,7 +722,7 @@ def test_split_bf16_conv3x3_epilogue_statistics_and_slices(vo):
     assert (mean_k - mean_o).abs().max().item() < 1e-7 * mean_o.abs().max().item()
     assert ((var_k - var_o).abs() / var_o).max().item() < 1e-3 and (mean_o.abs() / var_o.sqrt()).min().item() > 3
     # the input normalised + ReLU-ed while it is staged
-    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (2, 64, 33, 46, 64), (1, 128, 30, 40, 128)]:
+    for (N, C, H, W, K) in [(2, 16, 21, 28, 40), (2, 64, 33, 46, 64), (1, 128, 30, 40, 128), (1, 256, 30, 40, 64), (2, 48, 50, 74, 40)]:
         z = (_rand(N, C, H, W, seed=95, scale=2.0) + 0.7).to(DEV)
         w = (_rand(K, C, 3, 3, seed=96) / 12).to(DEV)
         st = torch.stack([z.double().sum((2, 3)), (z.double() ** 2).sum((2, 3))], dim=2).contiguous()
@@ -741,7 +742,7 @@ def test_split_bf16_conv3x3_epilogue_statistics_and_slices(vo):
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(1, 16, 5, 8, 64), (2, 32, 33, 22, 40), (2, 64, 60, 80, 126), (1, 16, 1, 2, 33),
-                                       (2, 384, 30, 40, 256), (1, 48, 70, 4, 32), (3, 384, 60, 80, 128)])
+                                       (2, 384, 30, 40, 256), (1, 48, 70, 4, 32), (3, 384, 60, 80, 128), (2, 32, 50, 74, 33)])
 @pytest.mark.parametrize("vertical", [False, True])
 def test_split_bf16_conv5_matches_direct_convolution(vo, N, C, H, W, K, vertical):
     """1x5 / 5x1 GRU gate convolutions on the split-bf16 direct kernel against the float64 direct

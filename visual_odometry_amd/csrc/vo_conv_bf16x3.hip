@@ -39,17 +39,20 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CK = 16;                        // input channels per chunk (the k of one matrix instruction)
 constexpr int KB = 64;                        // output channels per workgroup
-constexpr int TW = 32;                        // output columns of a workgroup's tile (one matrix tile of pixels per row)
 constexpr int NT = 256;                       // threads per workgroup
 constexpr int A_TAP = 2 * 2 * 64 * 16;        // bytes of weights per (chunk, tap): [part][m-tile][lane][16]
-constexpr int MAX_NORM_C = 256;
 
-// Filter R x S, stride ST; NTW = output rows per wave (TH = 4*NTW rows per workgroup).
-template <int R_, int S_, int ST_, int NTW_>
+// Filter R x S, stride ST; NTW = pixel tiles per wave; a pixel tile (the 32 columns of one matrix tile) is
+// one output row x 32 columns (TW = 32) or two rows x 16 columns (TW = 16, for maps whose width fills
+// 16-column blocks better: 80 columns are 5 x 16 but 3 x 32).  The workgroup's tile is TH rows x TW columns.
+template <int R_, int S_, int ST_, int NTW_, int TW_ = 32>
 struct Geo {
-    static constexpr int R = R_, S = S_, ST = ST_, NTW = NTW_;
+    static constexpr int R = R_, S = S_, ST = ST_, NTW = NTW_, TW = TW_;
     static constexpr int TAPS = R * S;
-    static constexpr int TH = 4 * NTW;
+    static constexpr int PH = 32 / TW;                                        // rows of a pixel tile
+    static constexpr int TH = 4 * NTW * PH;
+    static_assert(TW == 32 || (TW == 16 && ST == 1), "two-row pixel tiles are written for stride 1");
+    static constexpr int MAX_NORM_C = TW == 32 ? 256 : 128;                   // normalise-on-load table (what LDS leaves room for)
     static constexpr int PAD_H = R / 2, PAD_W = S / 2;
     static constexpr int SLACK = PAD_W & 1;                                   // the patch starts at an even input column
     static constexpr int RS = R == 1 ? ST : 1;                                // input rows between patch rows (a one-row filter skips the rows a stride passes over)
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     constexpr int A_CHUNK = G::A_CHUNK, A_PIECES = G::A_PIECES, TAPS = G::TAPS, STEPS = G::STEPS;
     // patch | weights of the chunk | (NORM_IN) per-channel scale and shift.  The reduction buffer of the
     // statistics epilogue re-uses the patch area after the last chunk.
-    __shared__ __align__(16) unsigned char lds[4 * PLANE + A_CHUNK + (NORM_IN ? MAX_NORM_C * 8 : 0)];
+    __shared__ __align__(16) unsigned char lds[4 * PLANE + A_CHUNK + (NORM_IN ? G::MAX_NORM_C * 8 : 0)];
     float2* nrm = reinterpret_cast<float2*>(lds + 4 * PLANE + A_CHUNK);
     double* red = reinterpret_cast<double*>(lds);                            // [2][4 waves][64]
     static_assert(4 * PLANE >= 4 * 4096, "the epilogue's transposition slots and the reduction buffer do not fit the patch area");
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     const int by = bid % blocks_y;
     const int n = bid / blocks_y;
     const int nchunks = C / CK;
-    const int y0 = by * G::TH, x0 = bx * TW;                                 // output pixel origin
+    const int y0 = by * G::TH, x0 = bx * G::TW;                              // output pixel origin
     const int HW4 = H * W * 4, HWo4 = Ho * Wo * 4;
 
     const float* xn = x + (int64_t)n * C * H * W;
@@ -214,14 +217,15 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     // A fragment of (tap, part, mt): weights area + ((tap*2 + part)*2 + mt) KiB + 16*lane
     // B fragment of (tap r, s), pixel tile nt: patch row (NTW*wave + nt)*stride + r, patch column (lane & 31)*stride + s + slack
     const unsigned char* a_lds = lds + 4 * PLANE + lane * 16;
-    const unsigned char* b_lds = lds + (lane >> 5) * PLANE + ((NTW * wave * G::ST / G::RS) * PC + (lane & 31)) * 16;
+    const int prow = (lane & 31) / G::TW, pcol = (lane & 31) % G::TW;        // this lane's pixel inside a pixel tile
+    const unsigned char* b_lds = lds + (lane >> 5) * PLANE + (((NTW * wave * G::PH + prow) * G::ST / G::RS) * PC + pcol) * 16;
     auto read_a = [&](int tap, int part, int mt) {
         return *reinterpret_cast<const bf16x8*>(a_lds + ((tap * 2 + part) * 2 + mt) * 1024);
     };
     auto read_b = [&](int tap, int nt, int part) {
         const int r = tap / G::S, c = tap % G::S + G::SLACK;                 // lane n reads patch column n*stride + c
         const int pos = G::ST == 1 ? c : (c & 1) * (PC / 2) + (c >> 1);
-        return *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PLANE + (((nt * G::ST + r) / G::RS) * PC + pos) * 16);
+        return *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PLANE + (((nt * G::PH * G::ST + r) / G::RS) * PC + pos) * 16);
     };
 
     // a chunk's weights are a linear copy (they are stored in operand order); they are requested at the
@@ -290,8 +294,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(yn, 0, K * HWo4, 0x00020000);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(ep.skip ? ep.skip + (int64_t)n * K * Ho * Wo : x), 0, ep.skip ? K * HWo4 : 0, 0x00020000);
-    const int col = x0 + (lane & 31), lh = lane >> 5;
-    const int row0 = y0 + NTW * wave;
+    const int col = x0 + pcol, lh = lane >> 5;
+    const int row0 = y0 + NTW * G::PH * wave + prow;                         // this lane's row of pixel tile 0
 
     if (ep.stats) {
         // plane sums of the raw output: per lane over its four rows, then over the 32 pixel lanes by a
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 float a1 = 0.0f, a2 = 0.0f;
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
-                    const bool ok = row0 + nt < Ho && col < Wo;
+                    const bool ok = row0 + nt * G::PH < Ho && col < Wo;
                     const float v = ok ? acc[mt][nt][e] : 0.0f;
                     a1 += v; a2 = fmaf(v, v, a2);
                 }
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         if (ep.stats) __syncthreads();                                       // the reduction buffer lies in the same area
         float* slot = reinterpret_cast<float*>(lds) + wave * 1024;
         const int q = lane >> 3, px4 = (lane & 7) * 4;                       // read-back role: channel rows q + 8j, pixels px4..px4+3
-        const int colw = x0 + px4;
+        const int colw = x0 + px4 % G::TW, roww = y0 + NTW * G::PH * wave + px4 / G::TW;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float sc[4], sh[4];
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
             }
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                const int row = row0 + nt;
+                const int row = roww + nt * G::PH;
                 const bool pok = row < Ho && colw < Wo;
                 const int poff = (row * Wo + colw) * 4;
                 u32x4 sk[4];
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int row = row0 + nt;
+            const int row = row0 + nt * G::PH;
             const bool pok = row < Ho && col < Wo;
             const int poff = (row * Wo + col) * 4;
             float sk[16];
@@ -474,9 +478,9 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
         return vo_fail(VO_ERR_UNSUPPORTED, "%s: needs an even width and an 8-byte aligned input (W=%d)", name, W);
     if ((int64_t)C * H * W * 4 >= 0x7fffffffLL || (int64_t)K * Ho * Wo * 4 >= 0x7fffffffLL)
         return vo_fail(VO_ERR_UNSUPPORTED, "%s: one image of the input or output exceeds 2 GiB", name);
-    if (in_stats && C > MAX_NORM_C)
-        return vo_fail(VO_ERR_UNSUPPORTED, "%s: normalise-on-load supports at most %d input channels", name, MAX_NORM_C);
-    const int bx = (Wo + TW - 1) / TW, by = (Ho + G::TH - 1) / G::TH;
+    if (in_stats && C > G::MAX_NORM_C)
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: normalise-on-load supports at most %d input channels", name, G::MAX_NORM_C);
+    const int bx = (Wo + G::TW - 1) / G::TW, by = (Ho + G::TH - 1) / G::TH;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
@@ -504,6 +508,15 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
 using Geo3x3 = Geo<3, 3, 1, 4>;
 using Geo1x5 = Geo<1, 5, 1, 4>;
 using Geo5x1 = Geo<5, 1, 1, 4>;
+using Geo3x3n = Geo<3, 3, 1, 4, 16>;          // 32 rows x 16 columns per workgroup
+using Geo1x5n = Geo<1, 5, 1, 4, 16>;
+using Geo5x1n = Geo<5, 1, 1, 4, 16>;
+
+// true when 32 x 16 blocks cover an H x W map with less waste than 16 x 32 blocks
+inline bool narrow_blocks_fit_better(int H, int W) {
+    auto up = [](int v, int m) { return (int64_t)((v + m - 1) / m * m); };
+    return up(H, 32) * up(W, 16) < up(H, 16) * up(W, 32);
+}
 using Geo3x3s2 = Geo<3, 3, 2, 1>;
 using Geo1x1s2 = Geo<1, 1, 2, 1>;
 
@@ -516,6 +529,9 @@ extern "C" int vo_conv3x3_bf16x3_filter(const float* weight, void* arranged, int
 extern "C" int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
                                  const float* scale, const float* shift, int relu, const float* skip, double* stats,
                                  const double* in_stats, float in_eps, int N, int C, int H, int W, int K, void* stream) {
+    if (narrow_blocks_fit_better(H, W) && !(in_stats && C > Geo3x3n::MAX_NORM_C))
+        return launch_conv<Geo3x3n>("vo_conv3x3_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, skip, stats, in_stats,
+                                    in_eps, N, C, H, W, K, vo_stream(stream));
     return launch_conv<Geo3x3>("vo_conv3x3_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, skip, stats, in_stats,
                                in_eps, N, C, H, W, K, vo_stream(stream));
 }
@@ -526,6 +542,13 @@ extern "C" int vo_conv5_bf16x3_filter(const float* weight, void* arranged, int K
 
 extern "C" int vo_conv5_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
                                const float* shift, int relu, int N, int C, int H, int W, int K, int vertical, void* stream) {
+    if (narrow_blocks_fit_better(H, W)) {
+        if (vertical)
+            return launch_conv<Geo5x1n>("vo_conv5_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr,
+                                        nullptr, 0.0f, N, C, H, W, K, vo_stream(stream));
+        return launch_conv<Geo1x5n>("vo_conv5_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr,
+                                    0.0f, N, C, H, W, K, vo_stream(stream));
+    }
     if (vertical)
         return launch_conv<Geo5x1>("vo_conv5_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr,
                                    0.0f, N, C, H, W, K, vo_stream(stream));

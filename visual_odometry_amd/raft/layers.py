@@ -153,7 +153,7 @@ def _winograd_tile_for(H: int, W: int, C: int = 0) -> int:
     up = lambda v, m: (v + m - 1) // m * m
     covered4 = min(up(H, 16) * up(W, 32), up(H, 32) * up(W, 16))
     best = (4, covered4) if covered4 < 1.55 * up(H, 16) * up(W, 16) else (2, 1.55 * up(H, 16) * up(W, 16))
-    if _SPLIT_BF16 and C % 16 == 0 and C > 0 and W % 2 == 0 and up(H, 16) * up(W, 32) < 1.3 * best[1]:
+    if _SPLIT_BF16 and C % 16 == 0 and C > 0 and W % 2 == 0 and min(up(H, 16) * up(W, 32), up(H, 32) * up(W, 16)) < 1.3 * best[1]:
         return 1
     return best[0]
 
