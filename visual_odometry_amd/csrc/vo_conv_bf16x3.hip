@@ -487,9 +487,12 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
     const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats};
     const InputNorm nrm{in_stats, in_eps};
     const unsigned short* ag = static_cast<const unsigned short*>(arranged);
-    // a last block with at most 32 channels goes out as a launch of its own with one channel tile
+    // a last block with at most 32 channels goes out as a launch of its own with one channel tile --
+    // except for the stride-2 layers: their few input channels make them bound by reading the input, and
+    // a second launch would read it from memory a second time (blocks of one launch that differ only in
+    // their channel block run side by side and share the input through L2)
     const int rem = K % KB;
-    const int full = (rem >= 1 && rem <= 32) ? kblocks - 1 : kblocks;
+    const int full = (rem >= 1 && rem <= 32 && G::ST == 1) ? kblocks - 1 : kblocks;
     if (full > 0) {
         const dim3 grid((unsigned)(blocks * full));
         if (in_stats) conv_bf16x3_kernel<G, true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0);
