@@ -41,7 +41,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak
 # kernels whose float32 products are three bf16 matrix-core terms: their recorded FLOPs are the bf16
 # multiply-adds they issue (three per product), priced against the bf16 peak
-SPLIT_BF16_KERNELS = ("vo_conv3x3_bf16x3", "vo_conv5_bf16x3", "vo_conv3x3s2_bf16x3")
+SPLIT_BF16_KERNELS = ("vo_conv3x3_bf16x3", "vo_conv5_bf16x3", "vo_conv3x3s2_bf16x3", "vo_conv1x1s2_bf16x3", "vo_conv7x7_bf16x3",
+                      "vo_corr_volume_2d_bf16x3", "vo_corr_volume_1d_bf16x3")
 
 
 def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256):
@@ -57,6 +58,10 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
         "vo_corr_volume_2d": dict(launches=1, flops=2.0 * n * n * D * B, bytes=(2 * n * D + n * n) * f * B),
         "vo_corr_volume_1d": dict(launches=1, flops=2.0 * h4 * w4 * w4 * D * B,
                                   bytes=(2 * h4 * w4 * D + h4 * w4 * w4) * f * B),
+        # split-bf16 products: three bf16 multiply-adds per float32 product
+        "vo_corr_volume_2d_bf16x3": dict(launches=1, flops=6.0 * n * n * D * B, bytes=(2 * n * D + n * n) * f * B),
+        "vo_corr_volume_1d_bf16x3": dict(launches=1, flops=6.0 * h4 * w4 * w4 * D * B,
+                                         bytes=(2 * h4 * w4 * D + h4 * w4 * w4) * f * B),
         "vo_corr_pyramid_2d": dict(launches=1, bytes=B * n * sum(lv2) * f),
         "vo_corr_pyramid_1d": dict(launches=1, bytes=B * h4 * w4 * sum(lv1) * f),
         # coords + window out + the (2r+2)^2 patch each pixel needs per level
@@ -397,6 +402,15 @@ def main():
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ck["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
                          "avg_launch_us": ck["avg_us"], "traffic": pmc_traffic("vo_corr_volume_2d", B, H, W),
                          "mfma_util_pmc": mfma_util_from_profile("corr2d", B, H, W)}
+    cs = kernels.get("vo_corr_volume_2d_bf16x3")
+    if cs:
+        # with bf16 terms the contraction's bound is the store of the volume, not the matrix cores
+        roofline_corr = {"kernel": "vo_corr_volume_2d_bf16x3", "bound": "hbm", "achieved": cs["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": cs["GBps"] / HBM_PEAK_GBS, "avg_launch_us": cs["avg_us"],
+                         "bf16_TFLOPs": cs["TFLOPs"], "float32_equivalent_TFLOPs": cs["TFLOPs"] / 3.0,
+                         "traffic": pmc_traffic("vo_corr_volume_2d_bf16x3", B, H, W),
+                         "note": "split-bf16 products (three bf16 matrix-core terms per float32 product); the float32-instruction "
+                                 "kernel's figures are in the f32_mfma_only leg's run (--conv-arithmetic f32)"}
     roofline["alg_per_launch"] = (work[dom].get("flops") if roofline["bound"] == "mfma" else work[dom]["bytes"]) / work[dom]["launches"]
     hand_ms = sum(k["ms_per_step"] for k in kernels.values())
 

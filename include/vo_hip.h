@@ -305,6 +305,14 @@ int vo_corr_volume_2d(const float* fmap1, const float* fmap2, float* corr,
                       int batch, int H, int W, int D, void* stream);
 int vo_corr_volume_1d(const float* fmap1, const float* fmap2, float* corr,
                       int batch, int H, int W1, int W2, int D, void* stream);
+/* The same two volumes with every float32 product assembled from three bf16 matrix-core terms
+ * (al*bh + ah*bl + ah*bh, float32 accumulation: 16 significant bits per product, largest error about 5e-6 of
+ * the largest entry; exact on small integers): the bf16 instruction runs at 16 times the float32 one's rate, so
+ * the store of the volume becomes the bound. */
+int vo_corr_volume_2d_bf16x3(const float* fmap1, const float* fmap2, float* corr,
+                             int batch, int H, int W, int D, void* stream);
+int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, float* corr,
+                             int batch, int H, int W1, int W2, int D, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Correlation pyramid: levels 1..3 from level 0 in one pass (avg_pool 2x2 / 1x2,

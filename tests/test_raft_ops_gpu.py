@@ -27,21 +27,34 @@ def _nchw(pm):          # pixel-major (B,H,W,D) -> (B,D,H,W)
 
 # ---------------------------------------------------------------- correlation
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("B,H,W,D", [(2, 12, 20, 256), (1, 7, 10, 64), (1, 16, 16, 32), (1, 60, 80, 256)])
-def test_corr_volume_2d(vo, B, H, W, D):
+def test_corr_volume_2d(vo, B, H, W, D, split):
+    """Both arithmetics (float32 matrix instruction; three bf16 terms per product) against the float64
+    restatement: 2e-5 absolute on entries of order one (split measured 2-5e-6)."""
     from visual_odometry_amd import ops
     f1, f2 = _rand(B, H, W, D, seed=1), _rand(B, H, W, D, seed=2)
-    got = ops.corr_volume_2d(f1.to(DEV), f2.to(DEV))
+    got = ops.corr_volume_2d(f1.to(DEV), f2.to(DEV), split=split)
     assert got.shape == (B, H * W, H, W)
     want = raft_ref.corr_volume_2d(_nchw(f1).double(), _nchw(f2).double()).float()
-    assert (got.cpu() - want).abs().max().item() < 2e-5
-    # transposing the roles transposes the volume bit for bit (same k order, a*b == b*a)
-    swapped = ops.corr_volume_2d(f2.to(DEV), f1.to(DEV))
-    assert torch.equal(swapped.view(B, H * W, H * W).transpose(1, 2), got.view(B, H * W, H * W))
+    assert (got.cpu() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    if not split:
+        # transposing the roles transposes the volume bit for bit (same k order, a*b == b*a)
+        swapped = ops.corr_volume_2d(f2.to(DEV), f1.to(DEV))
+        assert torch.equal(swapped.view(B, H * W, H * W).transpose(1, 2), got.view(B, H * W, H * W))
+    else:
+        # features spanning many binades: every product keeps 16 significant bits
+        s1 = (f1 * torch.exp2(torch.randint(-10, 10, f1.shape).float())).to(DEV)
+        gots = ops.corr_volume_2d(s1, f2.to(DEV), split=True)
+        wants = raft_ref.corr_volume_2d(_nchw(s1.cpu()).double(), _nchw(f2).double())
+        assert (gots.cpu().double() - wants).abs().max().item() < 2e-5 * max(1.0, wants.abs().max().item())
+        assert torch.equal(gots, ops.corr_volume_2d(s1, f2.to(DEV), split=True))
 
 
-def test_corr_volume_exact_on_integers(vo):
-    """Small-integer features make every product and partial sum exact in float32:
+@pytest.mark.parametrize("split", [False, True])
+def test_corr_volume_exact_on_integers(vo, split):
+    """Small-integer features make every product and partial sum exact in float32 (and their high bf16
+    parts hold them whole, so the split arithmetic is exact too):
     any operand-layout or tile-index slip shows up as a wrong integer.  fmap2 is
     not symmetric in anything, so a transposed write cannot hide."""
     from visual_odometry_amd import ops
@@ -49,25 +62,26 @@ def test_corr_volume_exact_on_integers(vo):
     g = torch.Generator().manual_seed(3)
     f1 = torch.randint(-3, 4, (B, H, W, D), generator=g).float()
     f2 = torch.randint(-3, 4, (B, H, W, D), generator=g).float()
-    got = ops.corr_volume_2d(f1.to(DEV), f2.to(DEV)).cpu().view(H * W, H * W)
+    got = ops.corr_volume_2d(f1.to(DEV), f2.to(DEV), split=split).cpu().view(H * W, H * W)
     want = (f1.view(H * W, D).double() @ f2.view(H * W, D).double().T / 16.0).float()
     assert torch.equal(got, want)
     # 1-D flavour, widths that are not multiples of the 32-wide MFMA tile
     f1 = torch.randint(-3, 4, (2, 5, 50, 64), generator=g).float()
     f2 = torch.randint(-3, 4, (2, 5, 37, 64), generator=g).float()
-    got = ops.corr_volume_1d(f1.to(DEV), f2.to(DEV)).cpu()
+    got = ops.corr_volume_1d(f1.to(DEV), f2.to(DEV), split=split).cpu()
     want = (torch.einsum("bhid,bhjd->bhij", f1.double(), f2.double()) / 8.0).float()
     assert got.shape == (2, 5, 50, 37) and torch.equal(got, want)
 
 
 @pytest.mark.parametrize("B,H,W,D", [(2, 6, 160, 256), (1, 3, 40, 256), (1, 2, 320, 256), (1, 2, 200, 128)])
-def test_corr_volume_1d(vo, B, H, W, D):
+@pytest.mark.parametrize("split", [False, True])
+def test_corr_volume_1d(vo, B, H, W, D, split):
     from visual_odometry_amd import ops
     f1, f2 = _rand(B, H, W, D, seed=4), _rand(B, H, W, D, seed=5)
-    got = ops.corr_volume_1d(f1.to(DEV), f2.to(DEV))
+    got = ops.corr_volume_1d(f1.to(DEV), f2.to(DEV), split=split)
     want = raft_ref.corr_volume_1d(_nchw(f1).double(), _nchw(f2).double()).float()
     assert got.shape == (B, H, W, W)
-    assert (got.cpu() - want).abs().max().item() < 2e-5
+    assert (got.cpu() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
 
 
 def test_corr_rejects_bad_input(vo):

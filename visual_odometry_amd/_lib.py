@@ -57,6 +57,8 @@ SIGNATURES = {
     "vo_prepare_images_gray": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_corr_volume_2d": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_1d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vo_corr_volume_2d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vo_corr_volume_1d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_corr_pyramid_2d": [_P, _P, _P, _P, _L, _I, _I, _P],
     "vo_corr_pyramid_1d": [_P, _P, _P, _P, _L, _I, _P],
     "vo_corr_lookup_2d": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

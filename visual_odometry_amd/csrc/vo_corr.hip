@@ -16,13 +16,29 @@
 // Which physical k feeds which (half, step) slot is irrelevant as long as A and B
 // agree, so each lane reads FOUR consecutive k values with one ds_read_b128
 // (k = 8*group + 4*(lane>>5) + step) and feeds them to four successive MFMAs.
+//
+// SPLIT variant (vo_corr_volume_*_bf16x3): the same tiling with every float32 product assembled from three
+// bf16 matrix-core terms (al*bh + ah*bl + ah*bh, float32 accumulation, 16 significant bits per
+// product): the staged slices are split into high and low bf16 parts on their way into LDS and a lane's
+// fragment is eight consecutive k of one part (one 16-byte read, v_mfma_f32_32x32x16_bf16).  The
+// bf16 instruction runs at 16 times the float32 instruction's rate, so the kernel's bound moves from
+// the matrix cores to the store of the volume.
 #include "vo_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PAD = 4;   // floats of row padding in LDS
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 p = __builtin_convertvector(v, bf16x2);          // round to nearest even
+    return __builtin_bit_cast(unsigned, p);
+}
 
 // Bijective XCD-aware remap: the dispatcher deals consecutive workgroups round
 // robin over the 8 XCDs; give each XCD one contiguous range of the work list so
@@ -33,8 +49,8 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + (bid >> 3);
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void corr_abt_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
     int64_t strideA, int64_t strideB, int64_t strideC, int tiles_m, int tiles_n, unsigned nwg, float divisor) {
     constexpr int THREADS = 64 * WAVES_M * WAVES_N;
@@ -46,6 +62,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
     static_assert(BM % (32 * WAVES_M) == 0 && BN % (32 * WAVES_N) == 0, "tile / wave mismatch");
     static_assert((BM * BK / 4) % THREADS == 0 && (BN * BK / 4) % THREADS == 0, "staging mismatch");
     static_assert(BK % 8 == 0, "BK must be a multiple of 8");
+    static_assert(!SPLIT || BK % 16 == 0, "the bf16 instruction takes 16 k per step");
+    // SPLIT: a row holds BK high parts then BK low parts (2 bytes each, as many bytes as BK floats); the
+    // same padding keeps the 16-byte fragment reads of 32 consecutive rows on distinct banks
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                   // [2][BM][LDS_STRIDE]
@@ -78,33 +97,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
 
     // staging: float4 slot f -> (row f / (BK/4), column group f % (BK/4)); rows past
     // the matrix edge re-read the last valid row (their products are never stored)
-    float4 ra[A_F4], rb[B_F4];
-#define VO_LOAD_SLICE(k0)                                                                                   \
+    float4 ra[2][A_F4], rb[2][B_F4];             // two slices in flight
+#define VO_LOAD_SLICE(set, k0)                                                                                   \
     do {                                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < A_F4; ++i_) {                                               \
             const int f_ = tid + i_ * THREADS;                                                              \
             const int r_ = min(row0 + f_ / (BK / 4), M - 1);                                                \
-            ra[i_] = *reinterpret_cast<const float4*>(Ag + (int64_t)r_ * K + (k0) + (f_ % (BK / 4)) * 4);   \
+            ra[set][i_] = *reinterpret_cast<const float4*>(Ag + (int64_t)r_ * K + (k0) + (f_ % (BK / 4)) * 4);   \
         }                                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < B_F4; ++i_) {                                               \
             const int f_ = tid + i_ * THREADS;                                                              \
             const int r_ = min(col0 + f_ / (BK / 4), N - 1);                                                \
-            rb[i_] = *reinterpret_cast<const float4*>(Bg + (int64_t)r_ * K + (k0) + (f_ % (BK / 4)) * 4);   \
+            rb[set][i_] = *reinterpret_cast<const float4*>(Bg + (int64_t)r_ * K + (k0) + (f_ % (BK / 4)) * 4);   \
         }                                                                                                   \
     } while (0)
-#define VO_STORE_SLICE(buf)                                                                                 \
+#define VO_STORE_SLICE(set, buf)                                                                               \
     do {                                                                                                    \
         float* as_ = As + (buf) * BM * LDS_STRIDE;                                                          \
         float* bs_ = Bs + (buf) * BN * LDS_STRIDE;                                                          \
         _Pragma("unroll") for (int i_ = 0; i_ < A_F4; ++i_) {                                               \
             const int f_ = tid + i_ * THREADS;                                                              \
-            *reinterpret_cast<float4*>(as_ + (f_ / (BK / 4)) * LDS_STRIDE + (f_ % (BK / 4)) * 4) = ra[i_];  \
+            store_f4(as_ + (f_ / (BK / 4)) * LDS_STRIDE, f_ % (BK / 4), ra[set][i_]);                          \
         }                                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < B_F4; ++i_) {                                               \
             const int f_ = tid + i_ * THREADS;                                                              \
-            *reinterpret_cast<float4*>(bs_ + (f_ / (BK / 4)) * LDS_STRIDE + (f_ % (BK / 4)) * 4) = rb[i_];  \
+            store_f4(bs_ + (f_ / (BK / 4)) * LDS_STRIDE, f_ % (BK / 4), rb[set][i_]);                          \
         }                                                                                                   \
     } while (0)
+    // four consecutive k of one row: as they are, or as four high parts (8 bytes at 2*k) and four low
+    // parts (8 bytes at 2*BK + 2*k)
+    auto store_f4 = [](float* row, int q, float4 v) {
+        if constexpr (SPLIT) {
+            const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
+            const unsigned l0 = pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
+            const unsigned l1 = pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
+            unsigned char* r = reinterpret_cast<unsigned char*>(row);
+            *reinterpret_cast<uint2*>(r + q * 8) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(r + 2 * BK + q * 8) = make_uint2(l0, l1);
+        } else {
+            *reinterpret_cast<float4*>(row + q * 4) = v;
+        }
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -113,10 +146,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
         for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
-
-    VO_LOAD_SLICE(0);
-    VO_STORE_SLICE(0);
-    __syncthreads();
 
     // one K-slice of MFMAs out of LDS buffer `buf`
 #define VO_MMA_SLICE(buf)                                                                                          \
@@ -138,19 +167,64 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
         }                                                                                                          \
     } while (0)
 
+    // SPLIT: lane (row lr, k-half lh) reads k = 16*kg + 8*lh .. +7 of each part
+    auto mma_split = [&](int buf) {
+        const unsigned char* as_ = reinterpret_cast<const unsigned char*>(As + buf * BM * LDS_STRIDE + (wm * TM * 32 + lr) * LDS_STRIDE) + 16 * lh;
+        const unsigned char* bs_ = reinterpret_cast<const unsigned char*>(Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + lr) * LDS_STRIDE) + 16 * lh;
+#pragma unroll
+        for (int kg = 0; kg < BK / 16; ++kg) {
+            bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+                    fa[part][m] = *reinterpret_cast<const bf16x8*>(as_ + m * 32 * LDS_STRIDE * 4 + part * 2 * BK + kg * 32);
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    fb[part][n] = *reinterpret_cast<const bf16x8*>(bs_ + n * 32 * LDS_STRIDE * 4 + part * 2 * BK + kg * 32);
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    // the small terms first, so that they are not rounded away against the large one
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[1][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
+                }
+        }
+    };
+#define VO_MMA(buf)                       \
+    do {                                  \
+        if constexpr (SPLIT) mma_split(buf); \
+        else VO_MMA_SLICE(buf);           \
+    } while (0)
+
+    // Slice s: global loads into register set s&1 two slices ahead (with bf16 terms a slice's multiply
+    // phase is shorter than the memory latency), LDS buffer s&1.  K is a multiple of 2*BK.
     const int slices = K / BK;
-    for (int s = 0; s + 1 < slices; ++s) {
-        const int buf = s & 1;
-        VO_LOAD_SLICE((s + 1) * BK);          // global loads in flight during the MFMAs below
-        VO_MMA_SLICE(buf);
-        VO_STORE_SLICE(buf ^ 1);              // the other buffer: nobody reads it in this phase
+    VO_LOAD_SLICE(0, 0);
+    VO_LOAD_SLICE(1, BK);
+    VO_STORE_SLICE(0, 0);
+    __syncthreads();
+    for (int s = 0; s < slices; s += 2) {
+        if (s + 2 < slices) VO_LOAD_SLICE(0, (s + 2) * BK);
+        VO_MMA(0);
+        VO_STORE_SLICE(1, 1);                 // slice s+1; the other buffer: nobody reads it in this phase
         __syncthreads();
+        if (s + 3 < slices) VO_LOAD_SLICE(1, (s + 3) * BK);
+        VO_MMA(1);
+        if (s + 2 < slices) {
+            VO_STORE_SLICE(0, 0);
+            __syncthreads();
+        }
     }
-    VO_MMA_SLICE((slices - 1) & 1);
+#undef VO_MMA
 #undef VO_MMA_SLICE
 #undef VO_LOAD_SLICE
 #undef VO_STORE_SLICE
 
+    const float inv_divisor = 1.0f / divisor;                    // SPLIT: no bit-for-bit claim to keep, one multiplication
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     // Per register the two wave halves each write 32 consecutive floats of one row.
 #pragma unroll
@@ -162,19 +236,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void corr_abt_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = rbase + (e & 3) + 8 * (e >> 2);
-                if (row < M && col < N) Cg[(int64_t)row * N + col] = acc[m][n][e] / divisor;
+                if (row < M && col < N) Cg[(int64_t)row * N + col] = SPLIT ? acc[m][n][e] * inv_divisor : acc[m][n][e] / divisor;
             }
         }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT>
 int launch_corr(const float* A, const float* B, float* C, int groups, int M, int N, int K, int64_t sA,
                 int64_t sB, int64_t sC, float divisor, hipStream_t stream, const char* name) {
     const int tiles_m = (int)vo_ceil_div(M, BM), tiles_n = (int)vo_ceil_div(N, BN);
     const int64_t nwg = (int64_t)tiles_m * tiles_n * groups;
     if (nwg > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: %lld workgroups", name, (long long)nwg);
     constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + PAD) * sizeof(float);
-    auto kern = corr_abt_kernel<BM, BN, BK, WAVES_M, WAVES_N>;
+    auto kern = corr_abt_kernel<BM, BN, BK, WAVES_M, WAVES_N, SPLIT>;
     if (lds > 48 * 1024) {
         // the attribute is kept per device and setting it is a cheap host call: set it on every
         // launch rather than remember it in a flag that another device or thread would not share
@@ -190,7 +264,7 @@ int launch_corr(const float* A, const float* B, float* C, int groups, int M, int
 }
 
 int corr_abt(const float* A, const float* B, float* C, int groups, int M, int N, int K, int64_t sA, int64_t sB,
-             int64_t sC, hipStream_t stream, const char* name) {
+             int64_t sC, hipStream_t stream, const char* name, bool split = false) {
     if (!A || !B || !C) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
     if (groups <= 0 || M <= 0 || N <= 0 || K <= 0)
         return vo_fail(VO_ERR_INVALID_ARG, "%s: non-positive size (groups=%d M=%d N=%d K=%d)", name, groups, M, N, K);
@@ -200,9 +274,16 @@ int corr_abt(const float* A, const float* B, float* C, int groups, int M, int N,
     const float divisor = sqrtf((float)K);      // corr / sqrt(dim), divided as the reference does
     // Small matrices (one image row of RAFT-Stereo) get one 160-wide tile per
     // workgroup; the big flow volume gets 128x128 tiles.
-    if (M <= 512 && N <= 512)
-        return launch_corr<160, 160, 16, 1, 5>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
-    return launch_corr<128, 128, 32, 2, 2>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+    // the kernels take K in pairs of slices: 2 x 16 for the small tile, 2 x 32 for the large one
+    const bool small = (M <= 512 && N <= 512) || K % 64 != 0;
+    if (split) {
+        if (small)
+            return launch_corr<160, 160, 16, 1, 5, true>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+        return launch_corr<128, 128, 32, 2, 2, true>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+    }
+    if (small)
+        return launch_corr<160, 160, 16, 1, 5, false>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+    return launch_corr<128, 128, 32, 2, 2, false>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
 }
 
 }  // namespace
@@ -222,4 +303,21 @@ extern "C" int vo_corr_volume_1d(const float* fmap1, const float* fmap2, float* 
     VO_REQUIRE((int64_t)batch * H <= 0x7fffffffLL, "vo_corr_volume_1d: batch*H too large");
     return corr_abt(fmap1, fmap2, corr, batch * H, W1, W2, D, (int64_t)W1 * D, (int64_t)W2 * D, (int64_t)W1 * W2,
                     vo_stream(stream), "vo_corr_volume_1d");
+}
+
+extern "C" int vo_corr_volume_2d_bf16x3(const float* fmap1, const float* fmap2, float* corr, int batch, int H, int W,
+                                        int D, void* stream) {
+    VO_REQUIRE(H > 0 && W > 0, "vo_corr_volume_2d_bf16x3: bad size H=%d W=%d", H, W);
+    const int64_t n = (int64_t)H * W;
+    VO_REQUIRE(n <= (1 << 20), "vo_corr_volume_2d_bf16x3: %lld pixels per feature map is beyond the supported 2^20", (long long)n);
+    return corr_abt(fmap1, fmap2, corr, batch, (int)n, (int)n, D, n * D, n * D, n * n, vo_stream(stream),
+                    "vo_corr_volume_2d_bf16x3", true);
+}
+
+extern "C" int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, float* corr, int batch, int H, int W1,
+                                        int W2, int D, void* stream) {
+    VO_REQUIRE(batch > 0 && H > 0, "vo_corr_volume_1d_bf16x3: bad size batch=%d H=%d", batch, H);
+    VO_REQUIRE((int64_t)batch * H <= 0x7fffffffLL, "vo_corr_volume_1d_bf16x3: batch*H too large");
+    return corr_abt(fmap1, fmap2, corr, batch * H, W1, W2, D, (int64_t)W1 * D, (int64_t)W2 * D, (int64_t)W1 * W2,
+                    vo_stream(stream), "vo_corr_volume_1d_bf16x3", true);
 }

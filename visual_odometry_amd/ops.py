@@ -680,27 +680,28 @@ def pyramid_shapes_2d(h2: int, w2: int, levels: int = MAX_LEVELS):
     return out
 
 
-def corr_volume_2d(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+def corr_volume_2d(fmap1: torch.Tensor, fmap2: torch.Tensor, split: bool = False) -> torch.Tensor:
     """All-pairs correlation of two pixel-major feature maps (B,H,W,D) ->
-    (B, H*W, H, W) float32, scaled by 1/sqrt(D)."""
+    (B, H*W, H, W) float32, scaled by 1/sqrt(D).  ``split``: every float32 product from three bf16
+    matrix-core terms (16 significant bits) instead of the float32 matrix instruction."""
     B, H, W, D = fmap1.shape
     if fmap2.shape != fmap1.shape:
         raise ValueError("fmap1 and fmap2 must have the same shape")
     corr = torch.empty((B, H * W, H, W), device=fmap1.device, dtype=torch.float32)
-    _call("vo_corr_volume_2d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
-              corr.data_ptr(), B, H, W, D, _stream())
+    _call("vo_corr_volume_2d_bf16x3" if split else "vo_corr_volume_2d", _dev(fmap1, "fmap1", torch.float32),
+          _dev(fmap2, "fmap2", torch.float32), corr.data_ptr(), B, H, W, D, _stream())
     return corr
 
 
-def corr_volume_1d(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
-    """Per-row all-pairs correlation (B,H,W1,D) x (B,H,W2,D) -> (B,H,W1,W2)."""
+def corr_volume_1d(fmap1: torch.Tensor, fmap2: torch.Tensor, split: bool = False) -> torch.Tensor:
+    """Per-row all-pairs correlation (B,H,W1,D) x (B,H,W2,D) -> (B,H,W1,W2); ``split`` as corr_volume_2d."""
     B, H, W1, D = fmap1.shape
     if fmap2.shape[0] != B or fmap2.shape[1] != H or fmap2.shape[3] != D:
         raise ValueError("fmap2 must be (B,H,W2,D) matching fmap1")
     W2 = fmap2.shape[2]
     corr = torch.empty((B, H, W1, W2), device=fmap1.device, dtype=torch.float32)
-    _call("vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
-              corr.data_ptr(), B, H, W1, W2, D, _stream())
+    _call("vo_corr_volume_1d_bf16x3" if split else "vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32),
+          _dev(fmap2, "fmap2", torch.float32), corr.data_ptr(), B, H, W1, W2, D, _stream())
     return corr
 
 

@@ -115,8 +115,14 @@ _WINOGRAD_TILE = 0          # 0: pick F(2x2,3x3) or F(4x4,3x3) per layer shape; 
 _SPLIT_BF16 = True          # 3x3 layers on the split-bf16 direct kernel where it applies (see conv_arithmetic)
 
 
+def split_bf16_on() -> bool:
+    """True when the heavy float32 products (convolutions, correlation volume) are assembled from three
+    bf16 matrix-core terms (see conv_arithmetic)."""
+    return _SPLIT_BF16
+
+
 def conv_arithmetic(kind: str) -> None:
-    """How the float32 3x3 convolutions form their products:
+    """How the float32 convolutions and the correlation volume form their products:
       "bf16x3" (default)  every float32 product from bf16 pieces, x*w ~ xl*wh + xh*wl + xh*wh, on the
                           bf16 matrix cores with float32 accumulation (16 significant bits per product,
                           largest error 4-6e-6 of a layer's largest output);

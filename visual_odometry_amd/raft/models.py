@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import BasicEncoder, MultiBasicEncoder, conv_plain, fused_passes
+from .layers import BasicEncoder, MultiBasicEncoder, conv_plain, fused_passes, split_bf16_on
 from .update import BasicMultiUpdateBlock, BasicUpdateBlock
 
 
@@ -102,7 +102,7 @@ class RAFTFlow(nn.Module):
             fmap1, fmap2 = both[: image1.shape[0]], both[image1.shape[0]:]
         B, H8, W8, _ = fmap1.shape
 
-        corr = ops.corr_volume_2d(fmap1, fmap2)
+        corr = ops.corr_volume_2d(fmap1, fmap2, split=split_bf16_on())
         pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
 
         act = self._act_dtype()
@@ -186,7 +186,7 @@ class RAFTStereo(nn.Module):
                         for i, conv in zip(inp_list, self.context_zqr_convs)]
         fmap1, fmap2 = both[:B], both[B:]
 
-        corr = ops.corr_volume_1d(fmap1, fmap2)
+        corr = ops.corr_volume_1d(fmap1, fmap2, split=split_bf16_on())
         pyramid = ops.corr_pyramid_1d(corr, c.corr_levels)
 
         _, _, h, w = net_list[0].shape
