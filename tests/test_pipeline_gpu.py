@@ -295,3 +295,36 @@ def test_chunk_with_device_rectification(vo):
     # MIOpen may pick another solver on the first call of a shape: rounding-level differences only
     assert torch.equal(a[1], b[1]) and torch.allclose(a[0][~a[1]], b[0][~b[1]], atol=1e-3)
     assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-3)
+
+
+def test_a_step_captures_into_a_hip_graph(vo):
+    """One whole step (both networks' refinement loops, depth, poses) records into a HIP graph -- no host
+    synchronisation, no allocation outside the capture pool, every launch on the current stream -- and
+    the replay gives the eager step's poses (to the run-to-run spread of the plane statistics' atomic sums),
+    also after the input frames change in place."""
+    H, W, F = 96, 128, 3
+    pipe = _vo(H, W, iters=3)
+    left, right = syn.stereo_sequence(21, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    _, _, cached = pipe.process_chunk(l, r, None)
+    T0, sk0, _ = pipe.process_chunk(l, r, cached)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.process_chunk(l, r, cached)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        T1, sk1, _ = pipe.process_chunk(l, r, cached)
+    g.replay()
+    torch.cuda.synchronize()
+    assert (T1 - T0).abs().max().item() < 1e-5 and torch.equal(sk1, sk0)
+    left2, right2 = syn.stereo_sequence(22, F, H, W)
+    l2, r2 = torch.from_numpy(left2).cuda(), torch.from_numpy(right2).cuda()
+    _, _, cached2 = pipe.process_chunk(l2, r2, None)
+    T2, sk2, _ = pipe.process_chunk(l2, r2, cached2)
+    l.copy_(l2); r.copy_(r2); cached.copy_(cached2)               # the graph reads the buffers it was recorded on
+    g.replay()
+    torch.cuda.synchronize()
+    assert (T1 - T2).abs().max().item() < 1e-5 and torch.equal(sk1, sk2) and (T2 - T0).abs().max().item() > 1e-3
