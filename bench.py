@@ -77,7 +77,9 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
 PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_corr_pyramid_2d": "pyr2d",
             "vo_corr_pyramid_1d": "pyr1d", "vo_corr_lookup_2d": "lookup2d", "vo_corr_lookup_1d": "lookup1d",
             "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4", "vo_conv5_winograd": "winograd1d",
-            "vo_conv3x3_bf16x3": "conv3x3_bf16x3"}
+            "vo_conv3x3_bf16x3": "conv3x3_bf16x3", "vo_conv3x3s2_bf16x3": "conv3x3s2_bf16x3", "vo_conv7x7_bf16x3": "conv7x7_bf16x3",
+            "vo_corr_volume_2d_bf16x3": "corr2d_bf16x3", "vo_corr_volume_1d_bf16x3": "corr1d_bf16x3",
+            "vo_instance_norm_apply": "instnorm_apply", "vo_conv1x1": "conv1x1"}
 
 
 def pmc_traffic(kernel: str, B: int, H: int, W: int):
@@ -236,7 +238,7 @@ def mfma_util_from_profile(kernel_key, B, H, W):
             continue
         meta = json.load(open(path))
         k = meta.get("kernels", {}).get(kernel_key)
-        if k and (meta.get("height"), meta.get("width")) == (H, W) and "mfma_busy_frac" in k:
+        if k and (meta.get("batch_pairs"), meta.get("height"), meta.get("width")) == (B, H, W) and "mfma_busy_frac" in k:
             return {"value": k["mfma_busy_frac"], "batch_pairs_of_the_pass": meta.get("batch_pairs"),
                     "source": "profiles/" + name}
     return None
@@ -262,6 +264,7 @@ def main():
                     help="skip the secondary float16-activation measurement")
     ap.add_argument("--no-config-legs", action="store_true",
                     help="skip the secondary measurements of the reference's default (full) argument set")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the measurement with frames uploaded from pinned host memory")
     ap.add_argument("--pose", choices=["svd", "ransac"], default="svd")
     ap.add_argument("--conv-arithmetic", choices=["bf16x3", "f32"], default="bf16x3",
                     help="how the heavy float32 convolutions multiply: three bf16 matrix-core terms per product "
@@ -389,6 +392,8 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
     roofline["traffic"] = pmc_traffic(dom, B, H, W)
+    if dom in PMC_KEYS and mfma_util_from_profile(PMC_KEYS[dom], B, H, W):
+        roofline["mfma_busy_pmc"] = mfma_util_from_profile(PMC_KEYS[dom], B, H, W)
     if dom in ("vo_conv3x3_winograd", "vo_conv3x3_winograd4"):
         # flops are the multiply-adds the kernel issues in the Winograd domain: 16 per 2x2 outputs
         # (4/9 of the direct form) for F(2x2,3x3), 36 per 4x4 outputs (1/4) for F(4x4,3x3)
@@ -442,7 +447,7 @@ def main():
             "kernels": kernels,
             "skipped_pairs_last_step": int(skipped.sum().item()),
         }
-        if world == 1:
+        if world == 1 and not args.no_upload_leg:
             # the same step with the chunk's frames coming from pinned host memory, uploaded on a second
             # stream one chunk ahead of the computation (what a caller holding host frames pays)
             reps = max(2, min(args.steps, 4))

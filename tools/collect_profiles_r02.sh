@@ -1,0 +1,32 @@
+#!/bin/bash
+# Profiles of the default bench workload (192 pairs per step) on a GPU box, run from the repository root:
+#   1. kernel trace + stats  -> gpurun_out/r02_bench_kernel_stats_top45.csv, r02_steady_state_step_breakdown.txt
+#   2. FETCH_SIZE and WRITE_SIZE in passes of their own, mean per launch and kernel -> r02_pmc_{FETCH,WRITE}_SIZE.json
+#   3. matrix-core busy cycles per kernel -> r02_pmc_mfma.json
+#   4. kernel trace of the reference's full argument set -> r02_full_args_step_breakdown.txt
+# tools/update_profiles_r02.py folds them into profiles/.
+set -e -o pipefail
+R=$(pwd)
+QUIET="--no-cpu-baseline --no-config-legs --no-mixed-precision-leg --no-upload-leg"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --steps 3 --warmup 1 $QUIET > $R/gpurun_out/r02_prof_bench.log 2>&1
+python3 $R/tools/step_breakdown.py $R/gpurun_out/prof_bench 45 > $R/gpurun_out/r02_steady_state_step_breakdown.txt
+f=$(ls $R/gpurun_out/prof_bench/*/*_kernel_stats.csv | head -1)
+head -46 $f | cut -c1-400 > $R/gpurun_out/r02_bench_kernel_stats_top45.csv
+rm -rf $R/gpurun_out/prof_bench
+echo "trace done"
+KERNELS=("Geo<3, 3, 1" "Geo<1, 5, 1" "Geo<5, 1, 1" "Geo<3, 3, 2" "Geo<1, 1, 2" "conv7_split_kernel" "corr_abt_kernel<128" "corr_abt_kernel<160" "lookup2d" "lookup1d" "pyramid2d" "pyramid1d" "instnorm_apply_kernel" "gru_gates" "gru_update" "conv1x1_kernel")
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 500 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_$c -- python3 $R/bench.py --steps 1 --warmup 0 $QUIET > $R/gpurun_out/r02_pmcb_$c.log 2>&1
+  python3 $R/tools/pmc_summary.py $R/gpurun_out/pmcb_$c "${KERNELS[@]}" > $R/gpurun_out/r02_pmc_$c.json
+  rm -rf $R/gpurun_out/pmcb_$c
+  echo "$c done"
+done
+timeout -s KILL 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmcb_mfma -- python3 $R/bench.py --steps 1 --warmup 0 $QUIET > $R/gpurun_out/r02_pmcb_mfma.log 2>&1
+python3 $R/tools/pmc_summary.py $R/gpurun_out/pmcb_mfma "${KERNELS[@]}" > $R/gpurun_out/r02_pmc_mfma.json
+rm -rf $R/gpurun_out/pmcb_mfma
+echo "mfma done"
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_full -- python3 $R/bench.py --stereo full --steps 2 --warmup 1 $QUIET > $R/gpurun_out/r02_prof_full.log 2>&1
+python3 $R/tools/step_breakdown.py $R/gpurun_out/prof_full 45 > $R/gpurun_out/r02_full_args_step_breakdown.txt
+rm -rf $R/gpurun_out/prof_full
+echo "all done"
