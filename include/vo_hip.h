@@ -194,6 +194,26 @@ int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, 
 int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
                         int N, int C, int H, int W, int K, void* stream);
+/* One step of a convolutional GRU (RAFT's SepConvGRU halves, RAFT-Stereo's ConvGRU; the update operators of the
+ * models built at flow/flow_map_RAFT.py:42 and stereo/stereo_disparity_RAFT.py:46) as TWO convolutions on the
+ * split-bf16 template with the gate arithmetic in their stores -- no pointwise pass, no concatenation:
+ *   vo_gru_conv_zr_bf16x3  x = [h | inputs] (N,Cin,H,W); weights = cat(W_z, W_r) (2C,Cin,taps) arranged by the filter
+ *                          entry point of the shape; bias (2C) = cat(b_z, b_r) or NULL; cz, cr (N,C,H,W) context terms
+ *                          with their batch strides, or NULL; h (N,C,H,W) with its batch stride.
+ *                          z_out (N,C,H,W) = sigmoid(conv_z + b_z + cz);  rh_out (N,C,H,W) = sigmoid(conv_r + b_r + cr) * h.
+ *   vo_gru_conv_q_bf16x3   the q convolution over [rh | x's channels C..] (x is the SAME buffer as above, its first C
+ *                          channels are not read); h_out (N,C,H,W) = (1 - z)*h + z*tanh(conv_q + b_q + cq); h_copy
+ *                          (or NULL; batch stride copy_batch_stride) receives the same values -- typically x's first C
+ *                          channels, ready for the next step.
+ * shape: 0 = 3x3 padding 1, 1 = 1x5 padding (0,2), 2 = 5x1 padding (2,0).  C a multiple of 64, Cin of 16, W of 4;
+ * every tensor 16-byte aligned, batch strides multiples of 4.  Replaces vo_conv* + vo_gru_gates / vo_gru_update. */
+int vo_gru_conv_zr_bf16x3(const float* x, const void* arranged, const float* bias, const float* cz, int64_t cz_batch_stride,
+                          const float* cr, int64_t cr_batch_stride, const float* h, int64_t h_batch_stride, float* z_out,
+                          float* rh_out, int N, int Cin, int H, int W, int C, int shape, void* stream);
+int vo_gru_conv_q_bf16x3(const float* x, const float* rh, const void* arranged, const float* bias, const float* cq,
+                         int64_t cq_batch_stride, const float* z, const float* h, int64_t h_batch_stride, float* h_out,
+                         float* h_copy, int64_t copy_batch_stride, int N, int Cin, int H, int W, int C, int shape, void* stream);
+
 /* 7x7 padding-3 convolution (stride 1 or 2) of a ONE- or TWO-channel input in the same arithmetic: the encoders'
  * stems on a gray frame (the wrappers' three equal channels folded into one, flow/flow_map_RAFT.py:96,101-102)
  * and the motion encoders' flow branch.  Bound by the store of its output: a workgroup walks four output rows

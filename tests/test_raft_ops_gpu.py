@@ -409,6 +409,39 @@ def test_fused_gru_steps_match_stock_operators(vo):
         assert (a[1] - b[1]).abs().max().item() < 1e-3 and (a[2] - b[2]).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("B,C,X,H,W", [(2, 128, 256, 60, 80), (1, 64, 192, 24, 64), (2, 64, 64, 15, 20), (1, 128, 128, 9, 36)])
+@pytest.mark.parametrize("ks", [(3, 3), (1, 5), (5, 1)])
+def test_gru_step_with_gates_in_the_convolution_store(vo, B, C, X, H, W, ks):
+    """vo_gru_conv_zr_bf16x3 + vo_gru_conv_q_bf16x3 (gate arithmetic in the convolutions' stores, r*h read by the q
+    convolution in place of the buffer's first channels) against the stock operators of one GRU step: both
+    block geometries, with and without context terms, the copy of the new state into the buffer slice."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    pad = (ks[0] // 2, ks[1] // 2)
+    h = torch.tanh(_rand(B, C, H, W, seed=200)).to(DEV)
+    x = _rand(B, X, H, W, seed=201).to(DEV)
+    wz, wr, wq = ((_rand(C, C + X, *ks, seed=202 + i) / (ks[0] * ks[1] * (C + X)) ** 0.5).to(DEV) for i in range(3))
+    bz, br, bq = (_rand(C, seed=205 + i).to(DEV) for i in range(3))
+    ctx_all = (_rand(B, 3 * C, H, W, seed=208) * 0.5).to(DEV)
+    for ctx in ((None, None, None), tuple(ctx_all.split(C, dim=1))):
+        buf = torch.cat([h, x], dim=1).contiguous()
+        hx = buf.double()
+        add = lambda t: 0.0 if t is None else t.double()
+        z = torch.sigmoid(Fn.conv2d(hx, wz.double(), bz.double(), 1, pad) + add(ctx[0]))
+        r = torch.sigmoid(Fn.conv2d(hx, wr.double(), br.double(), 1, pad) + add(ctx[1]))
+        q = torch.tanh(Fn.conv2d(torch.cat([r * h.double(), x.double()], dim=1), wq.double(), bq.double(), 1, pad) + add(ctx[2]))
+        want = ((1 - z) * h.double() + z * q).float()
+        Uzr = ops.gru_split_filter(torch.cat([wz, wr], dim=0).contiguous())
+        Uq = ops.gru_split_filter(wq)
+        zg, rh = ops.gru_conv_zr(buf, Uzr, torch.cat([bz, br]).contiguous(), ctx[0], ctx[1], h, ks)
+        assert (zg - z.float()).abs().max().item() < 2e-5 and (rh - (r * h.double()).float()).abs().max().item() < 2e-5
+        got = ops.gru_conv_q(buf, rh, Uq, bq, ctx[2], zg, h, ks, h_copy=buf[:, :C])
+        assert (got - want).abs().max().item() < 5e-5
+        assert torch.equal(buf[:, :C], got) and torch.equal(buf[:, C:], x)      # the state lands in the buffer, the inputs stay
+    with pytest.raises(Exception):
+        ops.gru_conv_zr(torch.cat([h, x], dim=1)[:, :, :, :W - 2].contiguous(), Uzr, None, None, None, h[:, :, :, :W - 2].contiguous(), ks)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 30, 40), (1, 2, 7, 9), (2, 4, 1, 1), (1, 3, 16, 22), (1, 1, 5, 64)])
 def test_avg_pool3x3s2_matches_avg_pool2d(vo, shape):
     """RAFT-Stereo's pool2x (3x3 / stride 2 / padding 1, padding counted) in float32 and float16

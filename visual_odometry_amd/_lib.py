@@ -40,6 +40,8 @@ SIGNATURES = {
     "vo_conv1x1s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_conv7x7_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv7x7_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_gru_conv_zr_bf16x3": [_P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_gru_conv_q_bf16x3": [_P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vo_winograd1d_filter": [_P, _P, _I, _I, _P],
     "vo_conv5_winograd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_filter": [_P, _P, _I, _I, _P],

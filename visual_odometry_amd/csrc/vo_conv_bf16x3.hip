@@ -98,13 +98,32 @@ __global__ __launch_bounds__(256) void filter_split_kernel(const float* __restri
 struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; double* stats; };
 struct InputNorm { const double* stats; float eps; };
 
+// Gate arithmetic of a convolutional GRU in the convolution's store (hidden width C, a multiple of 64):
+//   mode 1, the merged z|r convolution (2C output channels, shift = the two biases):
+//     channels < C :  z = sigmoid(conv + bias + a)          -> y   (N,C,Ho,Wo)
+//     channels >= C:  r*h = sigmoid(conv + bias + b) * h    -> out2 (N,C,Ho,Wo)
+//   mode 2, the q convolution (C output channels), whose first C INPUT channels come from `head` (= r*h)
+//   instead of x:   h' = (1 - z)*h + z*tanh(conv + bias + a) -> y (batch stride y_batch_stride) and out2 (copy)
+// a, b: the precomputed context terms (or null); h, z as named; *_bs = batch strides in elements.
+struct GruEp {
+    int mode, C;
+    const float* head;
+    const float* a; int64_t a_bs;
+    const float* b; int64_t b_bs;
+    const float* h; int64_t h_bs;
+    const float* z;
+    float* out2; int64_t out2_bs;
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 // MT: 32-channel tiles per workgroup (2: 64 output channels; 1: a last block of at most 32).
 // H, W: input size; Ho, Wo: output size.
-template <typename G, bool NORM_IN, int MT>
+template <typename G, bool NORM_IN, int MT, bool GRU = false>
 __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
                                                             float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H,
                                                             int W, int Ho, int Wo, int K, int blocks_x, int blocks_y,
-                                                            int kblocks, int kb_base) {
+                                                            int kblocks, int kb_base, GruEp gru) {
     constexpr int PLANE = G::PLANE, PC = G::PC, PR = G::PR, UNITS = G::UNITS, ROUNDS = G::ROUNDS, NTW = G::NTW;
     constexpr int A_CHUNK = G::A_CHUNK, A_PIECES = G::A_PIECES, TAPS = G::TAPS, STEPS = G::STEPS;
     // patch | weights of the chunk | (NORM_IN) per-channel scale and shift.  The reduction buffer of the
@@ -132,6 +151,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, C * HW4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(Ag) + (int64_t)kb * nchunks * (A_CHUNK / 2), 0, nchunks * A_CHUNK, 0x00020000);
+    // GRU mode 2: the first gru.C input channels are read from `head` (dense, gru.C planes per image)
+    const int head_chunks = (GRU && gru.head) ? gru.C / CK : 0;
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(head_chunks ? gru.head + (int64_t)n * gru.C * H * W : xn), 0, head_chunks ? gru.C * HW4 : 0, 0x00020000);
 
     // staging units of this thread: (k-half, patch row, column pair); a unit outside the image carries an
     // offset past the extent, which the range check of a buffer load turns into zeros (the padding)
@@ -167,7 +190,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
             if (i * NT + NT > UNITS && tid + i * NT >= UNITS) continue;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, u_off[i], (chunk * CK + j) * HW4, 0);
+                rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64((GRU && chunk < head_chunks) ? hrs : xrs, u_off[i], (chunk * CK + j) * HW4, 0);
         }
     };
     auto store_raw = [&](int chunk) {
@@ -353,6 +376,78 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         }
     }
 
+
+    if constexpr (GRU) {
+        // Gate arithmetic in the store (16-byte path only: the host checks Wo % 4 == 0 and the alignments).
+        float* slot = reinterpret_cast<float*>(lds) + wave * 1024;
+        const int q = lane >> 3, px4 = (lane & 7) * 4;
+        const int colw = x0 + px4 % G::TW, roww = y0 + NTW * G::PH * wave + px4 / G::TW;
+        const int CH = gru.C;
+        const bool second = gru.mode == 1 && kb * KB >= CH;                  // this workgroup's channels are r channels
+        const int cbase = kb * KB - (second ? CH : 0);
+        const int plane4 = CH * HWo4;                                        // bytes of one image of a C-channel tensor
+        const float* ctx = gru.mode == 1 ? (second ? gru.b : gru.a) : gru.a;
+        const int64_t ctx_bs = gru.mode == 1 ? (second ? gru.b_bs : gru.a_bs) : gru.a_bs;
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ctx ? ctx + (int64_t)n * ctx_bs : x), 0, ctx ? plane4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t h2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gru.h + (int64_t)n * gru.h_bs), 0, plane4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gru.z ? gru.z + (int64_t)n * CH * Ho * Wo : x), 0, gru.z ? plane4 : 0, 0x00020000);
+        // mode 1: z -> y, r*h -> out2 (both dense);  mode 2: h' -> y (its batch stride) and -> out2 (copy, its batch stride)
+        float* o1 = gru.mode == 1 ? (second ? gru.out2 + (int64_t)n * CH * Ho * Wo : y + (int64_t)n * CH * Ho * Wo) : y + (int64_t)n * ep.y_batch_stride;
+        float* o2 = (gru.mode == 2 && gru.out2) ? gru.out2 + (int64_t)n * gru.out2_bs : nullptr;
+        const __amdgpu_buffer_rsrc_t o1rs = __builtin_amdgcn_make_buffer_rsrc(o1, 0, plane4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t o2rs = __builtin_amdgcn_make_buffer_rsrc(o2 ? o2 : o1, 0, o2 ? plane4 : 0, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float sh[4];
+            int koff[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb * KB + mt * 32 + q + 8 * j;
+                sh[j] = ep.shift ? ep.shift[k] : 0.0f;
+                koff[j] = (cbase + mt * 32 + q + 8 * j) * HWo4;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int row = roww + nt * G::PH;
+                const bool pok = row < Ho && colw < Wo;
+                const int poff = (row * Wo + colw) * 4;
+                u32x4 cx[4], hh[4], zz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int off = pok ? koff[j] + poff : (int)0x80000000;
+                    cx[j] = __builtin_amdgcn_raw_buffer_load_b128(crs, off, 0, 0);              // zeros without context terms
+                    if (gru.mode == 2 || second) hh[j] = __builtin_amdgcn_raw_buffer_load_b128(h2rs, off, 0, 0);
+                    if (gru.mode == 2) zz[j] = __builtin_amdgcn_raw_buffer_load_b128(zrs, off, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) slot[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + (lane & 31)] = acc[mt][nt][e];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = *reinterpret_cast<const float4*>(slot + (q + 8 * j) * 32 + px4);
+                    float v[4] = {t.x, t.y, t.z, t.w};
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float pre = (v[i] + __uint_as_float(cx[j][i])) + sh[j];
+                        float r;
+                        if (gru.mode == 1) {
+                            r = sigmoid_f(pre);
+                            if (second) r *= __uint_as_float(hh[j][i]);
+                        } else {
+                            const float zv = __uint_as_float(zz[j][i]);
+                            r = (1.0f - zv) * __uint_as_float(hh[j][i]) + zv * tanhf(pre);
+                        }
+                        o[i] = __float_as_uint(r);
+                    }
+                    const int off = pok ? koff[j] + poff : (int)0x80000000;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, o1rs, off, 0, 0);
+                    if (gru.mode == 2) __builtin_amdgcn_raw_buffer_store_b128(o, o2rs, off, 0, 0);  // dropped when there is no copy
+                }
+            }
+        }
+        return;
+    }
+
     // Wide path: every tile passes through a 4 KiB LDS slot of its wave (32 channels x 32 pixels), so that a
     // lane ends up with four consecutive pixels of one channel: 16-byte stores (and residual loads), a
     // quarter of the store instructions, each wave-instruction covering eight full 128-byte segments.
@@ -495,13 +590,13 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
     const int full = (rem >= 1 && rem <= 32 && G::ST == 1) ? kblocks - 1 : kblocks;
     if (full > 0) {
         const dim3 grid((unsigned)(blocks * full));
-        if (in_stats) conv_bf16x3_kernel<G, true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0);
-        else conv_bf16x3_kernel<G, false, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0);
+        if (in_stats) conv_bf16x3_kernel<G, true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0, GruEp{});
+        else conv_bf16x3_kernel<G, false, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0, GruEp{});
     }
     if (full < kblocks) {
         const dim3 grid((unsigned)blocks);
-        if (in_stats) conv_bf16x3_kernel<G, true, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full);
-        else conv_bf16x3_kernel<G, false, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full);
+        if (in_stats) conv_bf16x3_kernel<G, true, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full, GruEp{});
+        else conv_bf16x3_kernel<G, false, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full, GruEp{});
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
@@ -522,6 +617,47 @@ inline bool narrow_blocks_fit_better(int H, int W) {
 }
 using Geo3x3s2 = Geo<3, 3, 2, 1>;
 using Geo1x1s2 = Geo<1, 1, 2, 1>;
+
+// GRU convolutions: shape 0 = 3x3 (padding 1), 1 = 1x5 (padding (0,2)), 2 = 5x1 (padding (2,0)); K output channels
+// in blocks of 64, gate arithmetic in the store (16-byte path).
+template <typename G>
+int launch_gru(const char* name, const float* x, const unsigned short* ag, float* y, int64_t y_batch_stride, const float* shift,
+               const GruEp& gru, int N, int C, int H, int W, int K, hipStream_t st) {
+    const int bx = (W + G::TW - 1) / G::TW, by = (H + G::TH - 1) / G::TH, kblocks = K / KB;
+    const int64_t blocks = (int64_t)bx * by * N * kblocks;
+    if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
+    const Epilogue ep{nullptr, shift, nullptr, 0, y_batch_stride, nullptr};
+    conv_bf16x3_kernel<G, false, 2, true><<<dim3((unsigned)blocks), dim3(NT), 0, st>>>(x, ag, y, ep, InputNorm{nullptr, 0.0f}, C, H, W, H, W, K,
+                                                                                     bx, by, kblocks, 0, gru);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
+    return VO_OK;
+}
+
+int gru_conv(const char* name, const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* shift,
+             const GruEp& gru, int N, int C, int H, int W, int K, int shape, hipStream_t st) {
+    if (!x || !arranged || !y || !gru.h) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes", name);
+    if (shape < 0 || shape > 2) return vo_fail(VO_ERR_INVALID_ARG, "%s: shape must be 0 (3x3), 1 (1x5) or 2 (5x1)", name);
+    if (gru.C <= 0 || gru.C % KB != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: hidden width %d is not a multiple of %d", name, gru.C, KB);
+    if (C % CK != 0 || W % 4 != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: needs input channels in multiples of %d and a width in multiples of 4", name, CK);
+    if ((int64_t)C * H * W * 4 >= 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: one image of the input exceeds 2 GiB", name);
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gru.head) |
+                           reinterpret_cast<uintptr_t>(gru.a) | reinterpret_cast<uintptr_t>(gru.b) | reinterpret_cast<uintptr_t>(gru.h) |
+                           reinterpret_cast<uintptr_t>(gru.z) | reinterpret_cast<uintptr_t>(gru.out2);
+    if ((ptrs & 15) != 0 || ((y_batch_stride | gru.a_bs | gru.b_bs | gru.h_bs | gru.out2_bs) & 3) != 0)
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: tensors must be 16-byte aligned with batch strides in multiples of 4", name);
+    const unsigned short* ag = static_cast<const unsigned short*>(arranged);
+    const bool narrow = narrow_blocks_fit_better(H, W);
+    switch (shape) {
+        case 0: return narrow ? launch_gru<Geo3x3n>(name, x, ag, y, y_batch_stride, shift, gru, N, C, H, W, K, st)
+                              : launch_gru<Geo3x3>(name, x, ag, y, y_batch_stride, shift, gru, N, C, H, W, K, st);
+        case 1: return narrow ? launch_gru<Geo1x5n>(name, x, ag, y, y_batch_stride, shift, gru, N, C, H, W, K, st)
+                              : launch_gru<Geo1x5>(name, x, ag, y, y_batch_stride, shift, gru, N, C, H, W, K, st);
+        default: return narrow ? launch_gru<Geo5x1n>(name, x, ag, y, y_batch_stride, shift, gru, N, C, H, W, K, st)
+                               : launch_gru<Geo5x1>(name, x, ag, y, y_batch_stride, shift, gru, N, C, H, W, K, st);
+    }
+}
 
 }  // namespace
 
@@ -573,4 +709,22 @@ extern "C" int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* 
                                    int relu, double* stats, int N, int C, int H, int W, int K, void* stream) {
     return launch_conv<Geo1x1s2>("vo_conv1x1s2_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, stats, nullptr, 0.0f, N, C,
                                  H, W, K, vo_stream(stream));
+}
+
+extern "C" int vo_gru_conv_zr_bf16x3(const float* x, const void* arranged, const float* bias, const float* cz, int64_t cz_batch_stride,
+                                     const float* cr, int64_t cr_batch_stride, const float* h, int64_t h_batch_stride, float* z_out,
+                                     float* rh_out, int N, int Cin, int H, int W, int C, int shape, void* stream) {
+    if (!rh_out) return vo_fail(VO_ERR_INVALID_ARG, "vo_gru_conv_zr_bf16x3: null pointer");
+    const GruEp gru{1, C, nullptr, cz, cz_batch_stride, cr, cr_batch_stride, h, h_batch_stride, nullptr, rh_out, (int64_t)C * H * W};
+    return gru_conv("vo_gru_conv_zr_bf16x3", x, arranged, z_out, (int64_t)C * H * W, bias, gru, N, Cin, H, W, 2 * C, shape, vo_stream(stream));
+}
+
+extern "C" int vo_gru_conv_q_bf16x3(const float* x, const float* rh, const void* arranged, const float* bias, const float* cq,
+                                    int64_t cq_batch_stride, const float* z, const float* h, int64_t h_batch_stride, float* h_out,
+                                    float* h_copy, int64_t copy_batch_stride, int N, int Cin, int H, int W, int C, int shape,
+                                    void* stream) {
+    if (!rh || !z) return vo_fail(VO_ERR_INVALID_ARG, "vo_gru_conv_q_bf16x3: null pointer");
+    if (h_out == h || h_copy == h) return vo_fail(VO_ERR_INVALID_ARG, "vo_gru_conv_q_bf16x3: the new state must not overwrite the tensor h is read from");
+    const GruEp gru{2, C, rh, cq, cq_batch_stride, nullptr, 0, h, h_batch_stride, z, h_copy, copy_batch_stride};
+    return gru_conv("vo_gru_conv_q_bf16x3", x, arranged, h_out, (int64_t)C * H * W, bias, gru, N, Cin, H, W, C, shape, vo_stream(stream));
 }

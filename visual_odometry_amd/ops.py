@@ -647,6 +647,65 @@ def gru_update(q: torch.Tensor, bias_q, cq, z: torch.Tensor, h: torch.Tensor, h_
     return h_out
 
 
+_GRU_SHAPES = {(3, 3): 0, (1, 5): 1, (5, 1): 2}
+
+
+def gru_split_filter(weight: torch.Tensor) -> torch.Tensor:
+    """(K,Cin,kh,kw) float32 GRU gate weights with (kh,kw) in 3x3 / 1x5 / 5x1 -> split-bf16 operands for
+    gru_conv_zr / gru_conv_q."""
+    ks = tuple(weight.shape[2:])
+    if ks == (3, 3):
+        return conv3x3_split_filter(weight)
+    if ks in ((1, 5), (5, 1)):
+        return conv5_split_filter(weight)
+    raise ValueError("GRU gate convolutions are 3x3, 1x5 or 5x1")
+
+
+def gru_conv_zr(buf: torch.Tensor, arranged: torch.Tensor, bias, cz, cr, h: torch.Tensor, kernel_size) -> tuple:
+    """The merged z|r convolution of a GRU step over buf = [h | inputs] with the gate arithmetic in its store:
+    returns (z, r*h), each (B,C,H,W).  ``arranged``: gru_split_filter(cat(W_z, W_r)); ``bias`` (2C) or None;
+    cz / cr context terms (B,C,H,W slices) or None."""
+    B, Cin, H, W = buf.shape
+    C = h.shape[1]
+    if tuple(h.shape) != (B, C, H, W):
+        raise ValueError("gru_conv_zr: h must be (B,C,H,W) matching buf")
+    shape = _GRU_SHAPES[tuple(kernel_size)]
+    taps = 9 if shape == 0 else 5
+    if arranged.numel() != 2 * C * Cin * taps or (bias is not None and bias.numel() != 2 * C):
+        raise ValueError("gru_conv_zr: weights / bias do not match (2C, Cin)")
+    z = torch.empty((B, C, H, W), device=buf.device, dtype=torch.float32)
+    rh = torch.empty((B, C, H, W), device=buf.device, dtype=torch.float32)
+    pcz, scz = _slice(cz, "cz", buf); pcr, scr = _slice(cr, "cr", buf); ph, sh = _slice(h, "h", buf)
+    _call("vo_gru_conv_zr_bf16x3", _dev(buf, "buf", torch.float32), _dev(arranged, "weights", torch.float32),
+          _opt(bias, "bias", torch.float32), pcz, scz, pcr, scr, ph, sh, z.data_ptr(), rh.data_ptr(), B, Cin, H, W, C, shape,
+          _stream(), nbytes=4 * (buf.numel() + 3 * z.numel() + z.numel() * ((cz is not None) + (cr is not None))),
+          flops=2 * 3 * taps * B * 2 * C * Cin * H * W)
+    return z, rh
+
+
+def gru_conv_q(buf: torch.Tensor, rh: torch.Tensor, arranged: torch.Tensor, bias, cq, z: torch.Tensor, h: torch.Tensor,
+               kernel_size, h_copy=None) -> torch.Tensor:
+    """The q convolution over [rh | buf[:, C:]] with the state update in its store: returns
+    h' = (1-z)*h + z*tanh(conv + bias + cq); ``h_copy`` (a (B,C,H,W) slice, typically buf[:, :C]) receives h' too."""
+    B, Cin, H, W = buf.shape
+    C = h.shape[1]
+    for t, n in ((rh, "rh"), (z, "z"), (h, "h")):
+        if tuple(t.shape) != (B, C, H, W):
+            raise ValueError(f"gru_conv_q: {n} must be (B,C,H,W) matching buf")
+    shape = _GRU_SHAPES[tuple(kernel_size)]
+    taps = 9 if shape == 0 else 5
+    if arranged.numel() != C * Cin * taps or (bias is not None and bias.numel() != C):
+        raise ValueError("gru_conv_q: weights / bias do not match (C, Cin)")
+    h_out = torch.empty((B, C, H, W), device=buf.device, dtype=torch.float32)
+    pcq, scq = _slice(cq, "cq", buf); ph, sh = _slice(h, "h", buf); pc, sc = _slice(h_copy, "h_copy", buf)
+    _call("vo_gru_conv_q_bf16x3", _dev(buf, "buf", torch.float32), _dev(rh, "rh", torch.float32),
+          _dev(arranged, "weights", torch.float32), _opt(bias, "bias", torch.float32), pcq, scq, _dev(z, "z", torch.float32),
+          ph, sh, h_out.data_ptr(), pc, sc, B, Cin, H, W, C, shape, _stream(),
+          nbytes=4 * (buf.numel() + z.numel() * (3 + (cq is not None) + (h_copy is not None))),
+          flops=2 * 3 * taps * B * C * Cin * H * W)
+    return h_out
+
+
 # ------------------------------------------------------------------ RAFT ops
 
 def pad_amounts(ht: int, wd: int, divis_by: int):

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .layers import conv2d_nobias, conv_act, conv_plain, fused_on, weight_for
+from .layers import conv2d_nobias, conv_act, conv_plain, fused_on, split_bf16_on, weight_for
 
 
 def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Conv2d, dtype) -> torch.Tensor:
@@ -29,9 +29,37 @@ def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Co
     return cached[1]
 
 
+def _split_gru_operands(owner, tag, convz, convr, convq):
+    """Split-bf16 operands of a GRU step's two convolutions (merged z|r weights and biases, q weights), cached
+    on the module; rebuilt if a weight or bias changes or moves."""
+    tensors = [convz.weight, convr.weight, convq.weight] + [c.bias for c in (convz, convr, convq) if c.bias is not None]
+    key = tuple((t._version, t.data_ptr()) for t in tensors)
+    cached = getattr(owner, "_vo_gru_split_" + tag, None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            Uzr = ops.gru_split_filter(torch.cat([convz.weight, convr.weight], dim=0).float().contiguous())
+            Uq = ops.gru_split_filter(convq.weight.float().contiguous())
+            bzr = None
+            if convz.bias is not None and convr.bias is not None:
+                bzr = torch.cat([convz.bias, convr.bias]).float().contiguous()
+        cached = (key, Uzr, bzr, Uq)
+        setattr(owner, "_vo_gru_split_" + tag, cached)
+    return cached[1], cached[2], cached[3]
+
+
 def _fused_gru_step(owner, tag, buf, h, C, convz, convr, convq, ctx=(None, None, None), h_copy=None):
-    """One GRU step on buf = [h | x] (B, C+X, H, W).  buf's first C channels are
-    overwritten with r*h for the q convolution; returns the new hidden state."""
+    """One GRU step on buf = [h | x] (B, C+X, H, W); returns the new hidden state (and leaves it in ``h_copy``).
+    Split-bf16 arithmetic: two convolutions with the gate arithmetic in their stores (buf is only read, r*h
+    goes to a tensor of its own which the q convolution reads in place of buf's first C channels).  Otherwise:
+    two bias-free convolutions and two pointwise passes, buf's first C channels overwritten with r*h in between."""
+    ks = tuple(convz.kernel_size)
+    if (split_bf16_on() and buf.dtype == torch.float32 and buf.is_contiguous() and h.is_contiguous() and C % 64 == 0
+            and buf.shape[1] % 16 == 0 and buf.shape[3] % 4 == 0 and ks in ((3, 3), (1, 5), (5, 1))
+            and tuple(convz.padding) == (ks[0] // 2, ks[1] // 2) and (convz.bias is None) == (convr.bias is None)
+            and buf.shape[1] * buf.shape[2] * buf.shape[3] * 4 < 2 ** 31 - 1):
+        Uzr, bzr, Uq = _split_gru_operands(owner, tag, convz, convr, convq)
+        z, rh = ops.gru_conv_zr(buf, Uzr, bzr, ctx[0], ctx[1], h, ks)
+        return ops.gru_conv_q(buf, rh, Uq, convq.bias, ctx[2], z, h, ks, h_copy)
     zr = conv2d_nobias(buf, _merged_zr_weight(owner, tag, convz, convr, buf.dtype), (1, 1), convz.padding)
     z = ops.gru_gates(zr, convz.bias, convr.bias, ctx[0], ctx[1], h, buf[:, :C])
     q = conv2d_nobias(buf, weight_for(convq, buf), (1, 1), convq.padding)
