@@ -191,6 +191,12 @@ int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y,
  * only the rows the stride lands on): weights (K,C) from vo_conv1x1_bf16x3_filter (ceil(K/64)*64 * C * 4 bytes),
  * epilogue or stats as vo_conv3x3s2_bf16x3. */
 int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+/* ... and the stride-1 1x1 convolution with many input and output channels (the motion encoders' first layer on the
+ * correlation window, the mask heads), where the float32 matrix instruction, not memory, bounds vo_conv1x1:
+ * same weights, epilogue (scale / shift / ReLU) and channel-slice output as vo_conv3x3_bf16x3. */
+int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
+                      const float* scale, const float* shift, int relu,
+                      int N, int C, int H, int W, int K, void* stream);
 int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
                         int N, int C, int H, int W, int K, void* stream);
@@ -353,12 +359,14 @@ int vo_corr_pyramid_1d(const float* l0, float* l1, float* l2, float* l3,
  * 1-D out: (B, levels*(2r+1), H, W); channel = l*(2r+1) + a samples the row at
  *          x/2^l + a - r (only coords channel 0 is read).
  * pyr[l] is level l as produced above; level sizes are floor-halved from (H2,W2).
+ * out_batch_stride: elements between the batch items of `out` (0 = dense); larger when `out` is the leading channels of
+ * a wider tensor, e.g. the window padded to a multiple of 16 channels for the convolution that consumes it.
  * ------------------------------------------------------------------------- */
 int vo_corr_lookup_2d(const float* l0, const float* l1, const float* l2, const float* l3,
-                      const float* coords, float* out, int batch, int H, int W,
+                      const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W,
                       int H2, int W2, int levels, int radius, void* stream);
 int vo_corr_lookup_1d(const float* l0, const float* l1, const float* l2, const float* l3,
-                      const float* coords, float* out, int batch, int H, int W,
+                      const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W,
                       int W2, int levels, int radius, void* stream);
 
 /* ---------------------------------------------------------------------------

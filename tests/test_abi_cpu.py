@@ -38,7 +38,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert lib.vo_corr_volume_2d(p, p, p, 1, 2, 2, 48, None) == _lib.VO_ERR_UNSUPPORTED   # D % 32 != 0
     assert b"multiple of 32" in lib.vo_last_error()
-    assert lib.vo_corr_lookup_2d(p, None, None, None, p, p, 1, 2, 2, 2, 2, 1, 7, None) == _lib.VO_ERR_UNSUPPORTED
+    assert lib.vo_corr_lookup_2d(p, None, None, None, p, p, 0, 1, 2, 2, 2, 2, 1, 7, None) == _lib.VO_ERR_UNSUPPORTED
     assert lib.vo_convex_upsample(p, p, p, 1, 2, 2, 2, 2, 3, 1.0, None) == _lib.VO_ERR_UNSUPPORTED
     assert lib.vo_corr_pyramid_2d(p, None, p, None, 1, 4, 4, None) == _lib.VO_ERR_INVALID_ARG
     with pytest.raises(ValueError):

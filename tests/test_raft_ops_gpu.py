@@ -909,6 +909,37 @@ def test_split_bf16_conv1x1s2_matches_the_stock_convolution(vo, N, C, H, W, K):
     assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
 
 
+@pytest.mark.parametrize("N,C,H,W,K", [(1, 64, 5, 8, 64), (2, 336, 60, 80, 256), (2, 128, 33, 70, 100), (1, 256, 15, 20, 576),
+                                       (2, 64, 9, 132, 144)])
+def test_split_bf16_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
+    """The many-channel 1x1 layers on the split-bf16 template against the float64 stock convolution: both block
+    geometries, partial channel blocks, fused bias + ReLU, channel-slice output; and a layer whose input was
+    padded with zero planes (the correlation window: 324 -> 336 channels) through its zero-extended twin."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    from visual_odometry_amd.raft import layers
+    x = _rand(N, C, H, W, seed=170).to(DEV)
+    w = (_rand(K, C, 1, 1, seed=171) / C ** 0.5).to(DEV)
+    bias = _rand(K, seed=172).to(DEV)
+    A = ops.conv1x1_split_filter(w)
+    want = Fn.conv2d(x.double(), w.double(), None)
+    tol = SPLIT_TOL * max(1.0, want.abs().max().item())
+    assert (ops.conv1x1_split(x, A, K).double() - want).abs().max().item() < tol
+    wide = torch.full((N, 3 + K + 2, H, W), 1.75, device=DEV)
+    ops.conv1x1_split(x, A, K, None, bias, True, out=wide[:, 3:3 + K])
+    ref = torch.relu(want.float() + bias[None, :, None, None])
+    assert (wide[:, 3:3 + K] - ref).abs().max().item() < 2 * tol
+    assert torch.all(wide[:, :3] == 1.75) and torch.all(wide[:, 3 + K:] == 1.75)
+    if C == 336:
+        conv = torch.nn.Conv2d(324, K, 1).to(DEV).eval()
+        xp = x.clone(); xp[:, 324:] = 0.0
+        with torch.no_grad():
+            want2 = torch.relu(conv(xp[:, :324].contiguous()))
+            with layers.fused_passes():
+                got2 = layers.conv_act(xp, layers.padded_input_twin(conv, 336))
+        assert (got2 - want2).abs().max().item() < 1e-4 * max(1.0, want2.abs().max().item())
+
+
 def test_instance_norm_join_normalises_a_raw_skip_branch(vo):
     """vo_instance_norm_apply with skip statistics: relu(act(norm(skip)) + relu(norm(x))) from two raw tensors
     and their plane sums, against the stock operators, with and without the ReLU on the skip branch."""

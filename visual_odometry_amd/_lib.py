@@ -37,6 +37,7 @@ SIGNATURES = {
     "vo_conv5_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv3x3s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_bf16x3_filter": [_P, _P, _I, _I, _P],
+    "vo_conv1x1_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_conv7x7_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv7x7_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -63,8 +64,8 @@ SIGNATURES = {
     "vo_corr_volume_1d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_corr_pyramid_2d": [_P, _P, _P, _P, _L, _I, _I, _P],
     "vo_corr_pyramid_1d": [_P, _P, _P, _P, _L, _I, _P],
-    "vo_corr_lookup_2d": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "vo_corr_lookup_1d": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_corr_lookup_2d": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_corr_lookup_1d": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vo_convex_upsample": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "vo_disparity_to_depth": [_P, _P, _L, _D, _I, _P],
     "vo_keypoints_to_3d": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -606,6 +606,8 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
 using Geo3x3 = Geo<3, 3, 1, 4>;
 using Geo1x5 = Geo<1, 5, 1, 4>;
 using Geo5x1 = Geo<5, 1, 1, 4>;
+using Geo1x1 = Geo<1, 1, 1, 4>;
+using Geo1x1n = Geo<1, 1, 1, 4, 16>;
 using Geo3x3n = Geo<3, 3, 1, 4, 16>;          // 32 rows x 16 columns per workgroup
 using Geo1x5n = Geo<1, 5, 1, 4, 16>;
 using Geo5x1n = Geo<5, 1, 1, 4, 16>;
@@ -727,4 +729,13 @@ extern "C" int vo_gru_conv_q_bf16x3(const float* x, const float* rh, const void*
     if (h_out == h || h_copy == h) return vo_fail(VO_ERR_INVALID_ARG, "vo_gru_conv_q_bf16x3: the new state must not overwrite the tensor h is read from");
     const GruEp gru{2, C, rh, cq, cq_batch_stride, nullptr, 0, h, h_batch_stride, z, h_copy, copy_batch_stride};
     return gru_conv("vo_gru_conv_q_bf16x3", x, arranged, h_out, (int64_t)C * H * W, bias, gru, N, Cin, H, W, C, shape, vo_stream(stream));
+}
+
+extern "C" int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
+                                 const float* shift, int relu, int N, int C, int H, int W, int K, void* stream) {
+    if (narrow_blocks_fit_better(H, W))
+        return launch_conv<Geo1x1n>("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr,
+                                    0.0f, N, C, H, W, K, vo_stream(stream));
+    return launch_conv<Geo1x1>("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr, 0.0f,
+                               N, C, H, W, K, vo_stream(stream));
 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int xs, 
 // re-reads the shared patch rows from L1 but multiplies the waves in flight.
 template <int R, int RPT>
 __global__ __launch_bounds__(256) void lookup2d_kernel(Levels lv, const float* __restrict__ coords,
-                                                       float* __restrict__ out, int64_t total, int HW, int levels) {
+                                                       float* __restrict__ out, int64_t out_bs, int64_t total, int HW, int levels) {
     constexpr int WIN = 2 * R + 1, T = 2 * R + 2, PARTS = WIN / RPT;
     static_assert(WIN % RPT == 0, "rows per lane must divide the window");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void lookup2d_kernel(Levels lv, const float* _
     const float* base;
     pick_level(lv, l, base, h, w);
     const float* img = base + (b * HW + p) * (int64_t)h * w;
-    float* o = out + (b * levels + l) * (int64_t)(WIN * WIN) * HW + p;
+    float* o = out + b * out_bs + l * (int64_t)(WIN * WIN) * HW + p;
 
     const float wx1 = fx, wx0 = 1.0f - fx, wy1 = fy, wy0 = 1.0f - fy;
     const int j0 = part * RPT;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void lookup2d_kernel(Levels lv, const float* _
 
 template <int R>
 __global__ __launch_bounds__(256) void lookup1d_kernel(Levels lv, const float* __restrict__ coords,
-                                                       float* __restrict__ out, int64_t total, int HW, int levels) {
+                                                       float* __restrict__ out, int64_t out_bs, int64_t total, int HW, int levels) {
     constexpr int WIN = 2 * R + 1, T = 2 * R + 2;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void lookup1d_kernel(Levels lv, const float* _
     const float* row = base + (b * HW + p) * (int64_t)w;
     float v[T];
     load_row<R>(row, x0 - R, w, true, v);
-    float* o = out + (b * levels + l) * (int64_t)WIN * HW + p;
+    float* o = out + b * out_bs + l * (int64_t)WIN * HW + p;
     const float wx1 = fx, wx0 = 1.0f - fx;
 #pragma unroll
     for (int a = 0; a < WIN; ++a) o[(int64_t)a * HW] = wx0 * v[a] + wx1 * v[a + 1];
@@ -158,8 +158,8 @@ int check_common(const char* fn, const float* const* lp, const float* coords, fl
 }  // namespace
 
 extern "C" int vo_corr_lookup_2d(const float* l0, const float* l1, const float* l2, const float* l3,
-                                 const float* coords, float* out, int batch, int H, int W, int H2, int W2, int levels,
-                                 int radius, void* stream) {
+                                 const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W, int H2,
+                                 int W2, int levels, int radius, void* stream) {
     const float* lp[VO_MAX_LEVELS] = {l0, l1, l2, l3};
     int rc = check_common("vo_corr_lookup_2d", lp, coords, out, batch, H, W, levels, radius);
     if (rc) return rc;
@@ -172,6 +172,8 @@ extern "C" int vo_corr_lookup_2d(const float* l0, const float* l1, const float* 
     }
     VO_REQUIRE(lv.h[levels - 1] > 0 && lv.w[levels - 1] > 0, "vo_corr_lookup_2d: level %d is empty", levels - 1);
     const int HW = H * W;
+    const int64_t out_bs = out_batch_stride ? out_batch_stride : (int64_t)levels * (2 * radius + 1) * (2 * radius + 1) * HW;
+    VO_REQUIRE(out_bs >= (int64_t)levels * (2 * radius + 1) * (2 * radius + 1) * HW, "vo_corr_lookup_2d: out_batch_stride smaller than one item");
     // One lane per (pair, level, pixel).  Splitting a window over 3 or 9 lanes was
     // measured slower (58 / 70 us against 52 us at 8 pairs of 640x480): the kernel is
     // bound by the cache lines it pulls in, and split lanes pull shared rows twice.
@@ -181,16 +183,16 @@ extern "C" int vo_corr_lookup_2d(const float* l0, const float* l1, const float* 
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = vo_stream(stream);
     if (radius == 4)
-        lookup2d_kernel<4, 9><<<grid, block, 0, st>>>(lv, coords, out, total, HW, levels);
+        lookup2d_kernel<4, 9><<<grid, block, 0, st>>>(lv, coords, out, out_bs, total, HW, levels);
     else
-        lookup2d_kernel<3, 7><<<grid, block, 0, st>>>(lv, coords, out, total, HW, levels);
+        lookup2d_kernel<3, 7><<<grid, block, 0, st>>>(lv, coords, out, out_bs, total, HW, levels);
     VO_CHECK_LAUNCH("vo_corr_lookup_2d");
     return VO_OK;
 }
 
 extern "C" int vo_corr_lookup_1d(const float* l0, const float* l1, const float* l2, const float* l3,
-                                 const float* coords, float* out, int batch, int H, int W, int W2, int levels,
-                                 int radius, void* stream) {
+                                 const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W, int W2,
+                                 int levels, int radius, void* stream) {
     const float* lp[VO_MAX_LEVELS] = {l0, l1, l2, l3};
     int rc = check_common("vo_corr_lookup_1d", lp, coords, out, batch, H, W, levels, radius);
     if (rc) return rc;
@@ -203,13 +205,15 @@ extern "C" int vo_corr_lookup_1d(const float* l0, const float* l1, const float* 
     }
     VO_REQUIRE(lv.w[levels - 1] > 0, "vo_corr_lookup_1d: level %d is empty", levels - 1);
     const int HW = H * W;
+    const int64_t out_bs = out_batch_stride ? out_batch_stride : (int64_t)levels * (2 * radius + 1) * HW;
+    VO_REQUIRE(out_bs >= (int64_t)levels * (2 * radius + 1) * HW, "vo_corr_lookup_1d: out_batch_stride smaller than one item");
     const int64_t total = (int64_t)batch * levels * HW;
     const int64_t blocks = vo_ceil_div(total, 256);
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_corr_lookup_1d: grid too large");
     if (radius == 4)
-        lookup1d_kernel<4><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, total, HW, levels);
+        lookup1d_kernel<4><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, out_bs, total, HW, levels);
     else
-        lookup1d_kernel<3><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, total, HW, levels);
+        lookup1d_kernel<3><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, out_bs, total, HW, levels);
     VO_CHECK_LAUNCH("vo_corr_lookup_1d");
     return VO_OK;
 }

@@ -403,6 +403,29 @@ def conv1x1_split_filter(weight: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def conv1x1_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+                  shift: torch.Tensor | None = None, relu: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """conv2d(x, weight(K,C,1,1)) on the split-bf16 direct kernel (weights from conv1x1_split_filter), optional
+    epilogue v*scale[k] + shift[k], ReLU; ``out``: a (N,K,H,W) channel slice that receives the result."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C:
+        raise ValueError("arranged weights do not match (K, C)")
+    if W % 2:
+        raise ValueError("the split-bf16 kernel needs an even width")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    if out is None:
+        out = torch.empty((N, K, H, W), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (N, K, H, W) or out.dtype != torch.float32:
+        raise ValueError("out must be a float32 (N,K,H,W) tensor or channel slice")
+    py, sy = _slice(out, "out")
+    _call("vo_conv1x1_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), py, sy,
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * 3 * N * K * C * H * W)
+    return out
+
+
 def conv1x1s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
                     shift: torch.Tensor | None = None, relu: bool = False, stats: torch.Tensor | None = None) -> torch.Tensor:
     """conv2d(x, weight(K,C,1,1), stride=2) on the split-bf16 direct kernel (weights from
@@ -811,10 +834,11 @@ def corr_lookup_2d(pyr, coords: torch.Tensor, radius: int = 4, out: torch.Tensor
     ch = len(pyr) * win * win
     if out is None:
         out = torch.empty((B, ch, H, W), device=coords.device, dtype=torch.float32)
-    elif tuple(out.shape) != (B, ch, H, W):
+    elif tuple(out.shape) != (B, ch, H, W) or out.dtype != torch.float32:
         raise ValueError("out has the wrong shape")
-    _call("vo_corr_lookup_2d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
-              _dev(out, "out", torch.float32), B, H, W, H2, W2, len(pyr), radius, _stream())
+    po, so = _slice(out, "out")                          # may be the leading channels of a wider tensor
+    _call("vo_corr_lookup_2d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32), po, so, B, H, W, H2, W2, len(pyr),
+          radius, _stream())
     return out
 
 
@@ -832,10 +856,11 @@ def corr_lookup_1d(pyr, coords: torch.Tensor, radius: int = 4, out: torch.Tensor
     ch = len(pyr) * (2 * radius + 1)
     if out is None:
         out = torch.empty((B, ch, H, W), device=coords.device, dtype=torch.float32)
-    elif tuple(out.shape) != (B, ch, H, W):
+    elif tuple(out.shape) != (B, ch, H, W) or out.dtype != torch.float32:
         raise ValueError("out has the wrong shape")
-    _call("vo_corr_lookup_1d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32),
-              _dev(out, "out", torch.float32), B, H, W, W2, len(pyr), radius, _stream())
+    po, so = _slice(out, "out")
+    _call("vo_corr_lookup_1d", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32), po, so, B, H, W, W2, len(pyr), radius,
+          _stream())
     return out
 
 

@@ -204,6 +204,24 @@ def _conv1x1_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
     return cached[1]
 
 
+def _conv1x1_split_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
+    """The cached split-bf16 weights when this 1x1 convolution has enough channels on both sides for the matrix
+    instruction, not memory, to bound the float32 streaming kernel (>= 64 in, >= 64 out, input channels a
+    multiple of 16, even width), else None."""
+    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+            and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (1, 1) and tuple(stride) == (1, 1)
+            and tuple(padding) == (0, 0) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
+            and x.shape[1] % 16 == 0 and x.shape[1] >= 64 and weight.shape[0] >= 64 and x.shape[3] % 2 == 0
+            and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1 and weight.shape[0] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
+        return None
+    key = (weight._version, weight.data_ptr())
+    cached = getattr(weight, "_vo_conv1x1_split", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.conv1x1_split_filter(weight))
+        weight._vo_conv1x1_split = cached
+    return cached[1]
+
+
 def _conv7x7_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached arranged weights when this convolution can run on the streaming 7x7 matrix-core
     kernel (7x7 / stride 1 or 2 / padding 3, at most 8 input channels, float32), else None."""
@@ -306,6 +324,9 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     U = _winograd_filter_for(x, weight, stride, padding, dilation, groups)
     if U is not None:
         return ops.conv3x3_winograd(x, U, weight.shape[0])
+    Ws = _conv1x1_split_weights_for(x, weight, stride, padding, dilation, groups)
+    if Ws is not None:
+        return ops.conv1x1_split(x, Ws, weight.shape[0])
     Wg = _conv1x1_weights_for(x, weight, stride, padding, dilation, groups)
     if Wg is not None:
         return ops.conv1x1(x, Wg, weight.shape[0])
@@ -354,6 +375,9 @@ def conv_affine_act(x: torch.Tensor, conv: nn.Conv2d, scale, shift: torch.Tensor
     if U is not None and (skip is None or (skip.dtype == torch.float32 and skip.is_contiguous())):
         return ops.conv3x3_winograd(x, U, w.shape[0], scale, shift, relu, skip, out)
     if skip is None:
+        Ws = _conv1x1_split_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if Ws is not None:
+            return ops.conv1x1_split(x, Ws, w.shape[0], scale, shift, relu, out)
         Wg = _conv1x1_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
         if Wg is not None:
             return ops.conv1x1(x, Wg, w.shape[0], scale, shift, relu, out)
@@ -520,6 +544,30 @@ def gray_stem(conv: nn.Conv2d, x: torch.Tensor) -> nn.Conv2d:
         twin.eval()
         cached = (key, twin)
         object.__setattr__(conv, "_vo_gray_twin", cached)          # not a registered sub-module: it holds no state of its own
+    return cached[1]
+
+
+def padded_input_twin(conv: nn.Conv2d, channels: int) -> nn.Conv2d:
+    """``conv`` for an input whose channel count was padded with zero planes to ``channels`` (a multiple of 16,
+    so that the layer can run on the split-bf16 kernels): a cached twin whose weights are zero-extended along
+    the input channels (rebuilt when the weights change or move).  Returns ``conv`` itself if nothing is padded."""
+    if channels == conv.in_channels:
+        return conv
+    if channels < conv.in_channels:
+        raise ValueError("the padded channel count is smaller than the layer's")
+    key = (channels, conv.weight._version, conv.weight.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()))
+    cached = getattr(conv, "_vo_padded_twin", None)
+    if cached is None or cached[0] != key:
+        twin = nn.Conv2d(channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=conv.bias is not None)
+        twin = twin.to(conv.weight.device)
+        with torch.no_grad():
+            twin.weight.zero_()
+            twin.weight[:, :conv.in_channels].copy_(conv.weight)
+            if conv.bias is not None:
+                twin.bias.copy_(conv.bias)
+        twin.eval()
+        cached = (key, twin)
+        object.__setattr__(conv, "_vo_padded_twin", cached)
     return cached[1]
 
 

@@ -116,8 +116,16 @@ class RAFTFlow(nn.Module):
             coords1 = coords1 + flow_init
         raw_mask = None
         state = {}                                               # the GRU's input buffer lives across iterations
+        # the window's 324 channels are padded with zero planes to a multiple of 16 when the consuming 1x1
+        # convolution runs on the split-bf16 kernel (which takes its input channels in chunks of 16)
+        win_ch = c.corr_levels * (2 * c.corr_radius + 1) ** 2
+        pad_ch = (-win_ch) % 16 if (split_bf16_on() and act == torch.float32 and W8 % 2 == 0) else 0
+        window_buf = torch.empty((B, win_ch + pad_ch, H8, W8), device=image1.device, dtype=torch.float32)
+        if pad_ch:
+            window_buf[:, win_ch:].zero_()
         for it in range(iters):
-            window = ops.corr_lookup_2d(pyramid, coords1.contiguous(), c.corr_radius)
+            ops.corr_lookup_2d(pyramid, coords1.contiguous(), c.corr_radius, out=window_buf[:, :win_ch])
+            window = window_buf
             flow = coords1 - coords0
             with fused_passes():
                 net, raw_mask, delta = self.update_block(net, inp, window.to(act), flow.to(act),

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .layers import conv2d_nobias, conv_act, conv_plain, fused_on, split_bf16_on, weight_for
+from .layers import conv2d_nobias, conv_act, conv_plain, fused_on, padded_input_twin, split_bf16_on, weight_for
 
 
 def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Conv2d, dtype) -> torch.Tensor:
@@ -159,10 +159,11 @@ class FlowMotionEncoder(nn.Module):
         if fused_on():
             B, _, H, W = flow.shape
             both = torch.empty((B, 192 + 64, H, W), device=flow.device, dtype=flow.dtype)    # [cor | flo], written in place
-            conv_act(conv_act(corr, self.convc1), self.convc2, out=both[:, :192])
+            # corr may carry zero planes behind the window (padded to a multiple of 16 channels)
+            conv_act(conv_act(corr, padded_input_twin(self.convc1, corr.shape[1])), self.convc2, out=both[:, :192])
             conv_act(conv_act(flow, self.convf1), self.convf2, out=both[:, 192:])
             return [conv_act(both, self.conv, out=out), flow]      # the GRU concatenates once, with its other inputs
-        cor = conv_act(conv_act(corr, self.convc1), self.convc2)
+        cor = conv_act(conv_act(corr[:, :self.convc1.in_channels], self.convc1), self.convc2)
         flo = conv_act(conv_act(flow, self.convf1), self.convf2)
         out = conv_act(torch.cat([cor, flo], dim=1), self.conv)
         return torch.cat([out, flow], dim=1)
