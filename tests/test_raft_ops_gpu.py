@@ -442,6 +442,28 @@ def test_gru_step_with_gates_in_the_convolution_store(vo, B, C, X, H, W, ks):
         ops.gru_conv_zr(torch.cat([h, x], dim=1)[:, :, :, :W - 2].contiguous(), Uzr, None, None, None, h[:, :, :, :W - 2].contiguous(), ks)
 
 
+def test_flow_update_block_with_folded_context_terms(vo):
+    """RAFT's update block over three iterations with the persistent buffer: the context features' share of the
+    six GRU gate convolutions is evaluated once and added in the convolutions' stores, the buffer holds
+    [h | motion | flow] only; against the stock operators iteration by iteration."""
+    from visual_odometry_amd.raft.layers import fused_passes
+    from visual_odometry_amd.raft.update import BasicUpdateBlock
+    torch.manual_seed(6)
+    B, H, W = 1, 24, 32
+    blk = BasicUpdateBlock().to(DEV).eval()
+    net0, inp = torch.tanh(_rand(B, 128, H, W, seed=230)).to(DEV), torch.relu(_rand(B, 128, H, W, seed=231)).to(DEV)
+    state, net_a, net_b = {}, net0.clone(), net0.clone()
+    for it in range(3):
+        corr, flow = _rand(B, 324, H, W, seed=232 + it).to(DEV), _rand(B, 2, H, W, seed=240 + it).to(DEV)
+        with torch.no_grad():
+            net_a, mask_a, delta_a = blk(net_a, inp, corr, flow, want_mask=True)
+            with fused_passes():
+                net_b, mask_b, delta_b = blk(net_b, inp, corr, flow, want_mask=True, state=state)
+        assert state["fold"] == (128, 256) and state["buf"].shape[1] == 256
+        for x, y in ((net_a, net_b), (mask_a, mask_b), (delta_a, delta_b)):
+            assert (x - y).abs().max().item() < 2e-4 * max(1.0, x.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 30, 40), (1, 2, 7, 9), (2, 4, 1, 1), (1, 3, 16, 22), (1, 1, 5, 64)])
 def test_avg_pool3x3s2_matches_avg_pool2d(vo, shape):
     """RAFT-Stereo's pool2x (3x3 / stride 2 / padding 1, padding counted) in float32 and float16

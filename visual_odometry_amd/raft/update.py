@@ -29,35 +29,55 @@ def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Co
     return cached[1]
 
 
-def _split_gru_operands(owner, tag, convz, convr, convq):
+def _split_gru_operands(owner, tag, convz, convr, convq, fold=None):
     """Split-bf16 operands of a GRU step's two convolutions (merged z|r weights and biases, q weights), cached
-    on the module; rebuilt if a weight or bias changes or moves."""
+    on the module; rebuilt if a weight or bias changes or moves.  ``fold`` = (lo, hi): the input channels
+    lo..hi-1 carry a tensor that does not change over the refinement iterations; they are cut out of the
+    step's weights and returned as separate (z|r, q) weights, whose convolution the caller evaluates once."""
     tensors = [convz.weight, convr.weight, convq.weight] + [c.bias for c in (convz, convr, convq) if c.bias is not None]
-    key = tuple((t._version, t.data_ptr()) for t in tensors)
+    key = (fold,) + tuple((t._version, t.data_ptr()) for t in tensors)
     cached = getattr(owner, "_vo_gru_split_" + tag, None)
     if cached is None or cached[0] != key:
         with torch.no_grad():
-            Uzr = ops.gru_split_filter(torch.cat([convz.weight, convr.weight], dim=0).float().contiguous())
-            Uq = ops.gru_split_filter(convq.weight.float().contiguous())
+            wzr = torch.cat([convz.weight, convr.weight], dim=0).float()
+            wq = convq.weight.float()
+            folded = None
+            if fold is not None:
+                lo, hi = fold
+                folded = (wzr[:, lo:hi].contiguous(), wq[:, lo:hi].contiguous())
+                wzr = torch.cat([wzr[:, :lo], wzr[:, hi:]], dim=1)
+                wq = torch.cat([wq[:, :lo], wq[:, hi:]], dim=1)
+            Uzr = ops.gru_split_filter(wzr.contiguous())
+            Uq = ops.gru_split_filter(wq.contiguous())
             bzr = None
             if convz.bias is not None and convr.bias is not None:
                 bzr = torch.cat([convz.bias, convr.bias]).float().contiguous()
-        cached = (key, Uzr, bzr, Uq)
+        cached = (key, Uzr, bzr, Uq, folded)
         setattr(owner, "_vo_gru_split_" + tag, cached)
-    return cached[1], cached[2], cached[3]
+    return cached[1], cached[2], cached[3], cached[4]
 
 
-def _fused_gru_step(owner, tag, buf, h, C, convz, convr, convq, ctx=(None, None, None), h_copy=None):
+def _split_gru_eligible(h: torch.Tensor, in_channels: int, convz: nn.Conv2d, convr: nn.Conv2d) -> bool:
+    """True when a GRU step over [h | x] with ``in_channels`` channels can run as two split-bf16 convolutions
+    with the gate arithmetic in their stores."""
+    ks = tuple(convz.kernel_size)
+    B, C, H, W = h.shape
+    return (split_bf16_on() and h.dtype == torch.float32 and h.is_cuda and h.is_contiguous() and C % 64 == 0
+            and in_channels % 16 == 0 and W % 4 == 0 and ks in ((3, 3), (1, 5), (5, 1))
+            and tuple(convz.padding) == (ks[0] // 2, ks[1] // 2) and (convz.bias is None) == (convr.bias is None)
+            and in_channels * H * W * 4 < 2 ** 31 - 1)
+
+
+def _fused_gru_step(owner, tag, buf, h, C, convz, convr, convq, ctx=(None, None, None), h_copy=None, fold=None):
     """One GRU step on buf = [h | x] (B, C+X, H, W); returns the new hidden state (and leaves it in ``h_copy``).
     Split-bf16 arithmetic: two convolutions with the gate arithmetic in their stores (buf is only read, r*h
     goes to a tensor of its own which the q convolution reads in place of buf's first C channels).  Otherwise:
-    two bias-free convolutions and two pointwise passes, buf's first C channels overwritten with r*h in between."""
+    two bias-free convolutions and two pointwise passes, buf's first C channels overwritten with r*h in between.
+    ``fold`` = (lo, hi): buf does NOT hold the model's input channels lo..hi-1; their contribution arrives in
+    ``ctx`` (see SepConvGRU.constant_terms) -- split-bf16 path only, the caller checked _split_gru_eligible."""
     ks = tuple(convz.kernel_size)
-    if (split_bf16_on() and buf.dtype == torch.float32 and buf.is_contiguous() and h.is_contiguous() and C % 64 == 0
-            and buf.shape[1] % 16 == 0 and buf.shape[3] % 4 == 0 and ks in ((3, 3), (1, 5), (5, 1))
-            and tuple(convz.padding) == (ks[0] // 2, ks[1] // 2) and (convz.bias is None) == (convr.bias is None)
-            and buf.shape[1] * buf.shape[2] * buf.shape[3] * 4 < 2 ** 31 - 1):
-        Uzr, bzr, Uq = _split_gru_operands(owner, tag, convz, convr, convq)
+    if fold is not None or (buf.dtype == torch.float32 and buf.is_contiguous() and _split_gru_eligible(h, buf.shape[1], convz, convr)):
+        Uzr, bzr, Uq, _ = _split_gru_operands(owner, tag, convz, convr, convq, fold)
         z, rh = ops.gru_conv_zr(buf, Uzr, bzr, ctx[0], ctx[1], h, ks)
         return ops.gru_conv_q(buf, rh, Uq, convq.bias, ctx[2], z, h, ks, h_copy)
     zr = conv2d_nobias(buf, _merged_zr_weight(owner, tag, convz, convr, buf.dtype), (1, 1), convz.padding)
@@ -98,18 +118,33 @@ class SepConvGRU(nn.Module):
         q = torch.tanh(convq(torch.cat([r * h, x], dim=1)))
         return (1 - z) * h + z * q
 
-    def forward(self, h, x, buf=None):
+    def constant_terms(self, const: torch.Tensor, lo: int):
+        """The part of the six gate convolutions that reads input channels lo..lo+K-1 = ``const`` (B,K,H,W), a
+        tensor that stays the same over all refinement iterations (RAFT's context features): evaluated once,
+        handed to every step as additive terms -- the per-iteration convolutions then run over a third fewer
+        input channels.  Returns ((cz1, cr1, cq1), (cz2, cr2, cq2)), channel slices of two tensors."""
+        C = self.convz1.out_channels
+        out = []
+        for tag, cz, cr, cq in (("1", self.convz1, self.convr1, self.convq1), ("2", self.convz2, self.convr2, self.convq2)):
+            _, _, _, folded = _split_gru_operands(self, tag, cz, cr, cq, (lo, lo + const.shape[1]))
+            both = torch.cat([conv2d_nobias(const, folded[0], (1, 1), cz.padding), conv2d_nobias(const, folded[1], (1, 1), cz.padding)], dim=1)
+            out.append(tuple(both.split(C, dim=1)))
+        return tuple(out)
+
+    def forward(self, h, x, buf=None, ctx=None, fold=None):
         """``x`` may be a tensor or a list of tensors that together form the input.  ``buf``
         (fused path): a (B, C+X, H, W) buffer whose channels C.. already hold the input and
         whose first C channels hold ``h``; it is left holding the NEW hidden state in its
-        first C channels, ready for the next iteration."""
+        first C channels, ready for the next iteration.  ``ctx`` / ``fold``: the terms of
+        ``constant_terms`` and the channel range they stand for (buf then holds the other inputs only)."""
         if fused_on() and h.is_cuda and h.dtype in (torch.float32, torch.float16):
             C = h.shape[1]
             if buf is None:
                 parts = list(x) if isinstance(x, (list, tuple)) else [x]
                 buf = torch.cat([h] + parts, dim=1)                      # the only copy of the step
-            h = _fused_gru_step(self, "1", buf, h, C, self.convz1, self.convr1, self.convq1, h_copy=buf[:, :C])
-            return _fused_gru_step(self, "2", buf, h, C, self.convz2, self.convr2, self.convq2, h_copy=buf[:, :C])
+            c1, c2 = ctx if ctx is not None else ((None, None, None), (None, None, None))
+            h = _fused_gru_step(self, "1", buf, h, C, self.convz1, self.convr1, self.convq1, c1, h_copy=buf[:, :C], fold=fold)
+            return _fused_gru_step(self, "2", buf, h, C, self.convz2, self.convr2, self.convq2, c2, h_copy=buf[:, :C], fold=fold)
         if isinstance(x, (list, tuple)):
             x = torch.cat(list(x), dim=1)
         h = self._step(h, x, self.convz1, self.convr1, self.convq1)
@@ -215,13 +250,25 @@ class BasicUpdateBlock(nn.Module):
             buf = state.get("buf")
             if buf is None:
                 B, _, H, W = net.shape
-                buf = torch.empty((B, C + X + 128, H, W), device=net.device, dtype=net.dtype)
+                # The context features do not change over the iterations: where the GRU runs on the split-bf16
+                # kernels their share of the gate convolutions is evaluated once (state["ctx"]) and the buffer
+                # holds [h | motion | flow] only; otherwise [h | context | motion | flow].
+                fold = (C, C + X) if (_split_gru_eligible(net.contiguous(), C + 128, self.gru.convz1, self.gru.convr1)
+                                      and inp.dtype == torch.float32) else None
+                state["fold"] = fold
+                keep = 0 if fold is not None else X
+                buf = torch.empty((B, C + keep + 128, H, W), device=net.device, dtype=net.dtype)
                 buf[:, :C].copy_(net)
-                buf[:, C:C + X].copy_(inp)
+                if fold is None:
+                    buf[:, C:C + X].copy_(inp)
+                else:
+                    state["ctx"] = self.gru.constant_terms(inp.contiguous(), C)
                 state["buf"] = buf
-            self.encoder(flow, corr, out=buf[:, C + X:C + X + 126])
-            buf[:, C + X + 126:].copy_(flow)
-            net = self.gru(net, None, buf=buf)
+            fold = state["fold"]
+            m0 = C + (0 if fold is not None else X)
+            self.encoder(flow, corr, out=buf[:, m0:m0 + 126])
+            buf[:, m0 + 126:].copy_(flow)
+            net = self.gru(net.contiguous(), None, buf=buf, ctx=state.get("ctx"), fold=fold)
         else:
             motion = self.encoder(flow, corr)
             if isinstance(motion, list):
