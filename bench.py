@@ -95,7 +95,9 @@ def pmc_traffic(kernel: str, B: int, H: int, W: int):
     k = meta["kernels"].get(PMC_KEYS[kernel])
     if not k:
         return None
-    return (2.0 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
+    # gathered reads (the lookups) are counted per touched 128-byte line, without the halving of wide streaming reads
+    fetch_factor = 1.0 if PMC_KEYS[kernel] in ("lookup2d", "lookup1d") else 2.0
+    return (fetch_factor * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024.0
 
 
 def mixed_precision_leg(vo32, vo16, left, right, cached, steps):

@@ -370,6 +370,28 @@ int vo_corr_lookup_1d(const float* l0, const float* l1, const float* l2, const f
                       int W2, int levels, int radius, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * The 2-D pyramid in a TILED target order (the lookup's patches then cost about half the cache lines).
+ * One source pixel's slice of a level of true size h x w: tiles of 8 columns x 4 rows (32 floats = one 128-byte
+ * line), tiles_x = ceil(w/8), tiles_y = ceil(h/4), element (y,x) at ((y>>2)*tiles_x + (x>>3))*32 + (y&3)*8 + (x&7);
+ * vo_tiled_slice_elements(h, w) = tiles_y*tiles_x*32.  Entries of a tile outside the true size are not values.
+ *   vo_tile_feature_rows      fmap (B,H*W,D) -> (B, slice, D): the second feature map with its rows in tiled order
+ *                             (zero rows for the padding); the correlation of fmap1 with it IS level 0, tiled:
+ *   vo_corr_volume_mn         corr[b][m][n] = <f1[b,m,:], f2[b,n,:]> / sqrt(D) for M x N pixels (split != 0: bf16x3).
+ *   vo_corr_pyramid_2d_tiled  levels 1..3 (tiled, sizes floor-halved) from tiled level 0 in one pass.
+ *   vo_corr_lookup_2d_tiled   vo_corr_lookup_2d on tiled levels; identical results.
+ * Same call sites in the reference as the row-major entry points above.
+ * ------------------------------------------------------------------------- */
+int64_t vo_tiled_slice_elements(int H2, int W2);
+int vo_tile_feature_rows(const float* fmap, float* out, int batch, int H, int W, int D, void* stream);
+int vo_corr_volume_mn(const float* fmap1, const float* fmap2, float* corr, int batch, int M, int N, int D, int split,
+                      void* stream);
+int vo_corr_pyramid_2d_tiled(const float* l0, float* l1, float* l2, float* l3,
+                             int64_t images, int H2, int W2, void* stream);
+int vo_corr_lookup_2d_tiled(const float* l0, const float* l1, const float* l2, const float* l3,
+                            const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W,
+                            int H2, int W2, int levels, int radius, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Convex upsampling (RAFT.upsample_flow / RAFTStereo.upsample_flow).
  * flow: (B,Cf,H,W); mask: (B, 9*f*f, H, W) raw logits times mask_scale;
  * out:  (B,Cout,f*H,f*W) with Cout <= Cf leading channels (stereo keeps 1).

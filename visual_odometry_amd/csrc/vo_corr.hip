@@ -321,3 +321,11 @@ extern "C" int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, 
     return corr_abt(fmap1, fmap2, corr, batch * H, W1, W2, D, (int64_t)W1 * D, (int64_t)W2 * D, (int64_t)W1 * W2,
                     vo_stream(stream), "vo_corr_volume_1d_bf16x3", true);
 }
+
+extern "C" int vo_corr_volume_mn(const float* fmap1, const float* fmap2, float* corr, int batch, int M, int N, int D, int split,
+                                 void* stream) {
+    VO_REQUIRE(M > 0 && N > 0, "vo_corr_volume_mn: bad size M=%d N=%d", M, N);
+    VO_REQUIRE(M <= (1 << 20) && N <= (1 << 21), "vo_corr_volume_mn: matrix sides beyond the supported 2^20 x 2^21");
+    return corr_abt(fmap1, fmap2, corr, batch, M, N, D, (int64_t)M * D, (int64_t)N * D, (int64_t)M * N, vo_stream(stream),
+                    "vo_corr_volume_mn", split != 0);
+}

@@ -102,6 +102,8 @@ class RAFTFlow(nn.Module):
             fmap1, fmap2 = both[: image1.shape[0]], both[image1.shape[0]:]
         B, H8, W8, _ = fmap1.shape
 
+        # row-major target order: the tiled order (ops.corr_*_tiled) gives identical values but was measured
+        # slower and heavier on the memory counters for the lookup's gathers
         corr = ops.corr_volume_2d(fmap1, fmap2, split=split_bf16_on())
         pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
 
