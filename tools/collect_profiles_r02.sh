@@ -15,7 +15,8 @@ f=$(ls $R/gpurun_out/prof_bench/*/*_kernel_stats.csv | head -1)
 head -46 $f | cut -c1-400 > $R/gpurun_out/r02_bench_kernel_stats_top45.csv
 rm -rf $R/gpurun_out/prof_bench
 echo "trace done"
-KERNELS=("Geo<3, 3, 1" "Geo<1, 5, 1" "Geo<5, 1, 1" "Geo<3, 3, 2" "Geo<1, 1, 2" "conv7_split_kernel" "corr_abt_kernel<128" "corr_abt_kernel<160" "lookup2d" "lookup1d" "pyramid2d" "pyramid1d" "instnorm_apply_kernel" "gru_gates" "gru_update" "conv1x1_kernel")
+# every kernel under its own (templated) name; tools/update_profiles_r02.py groups them by entry point
+KERNELS=()
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 500 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_$c -- python3 $R/bench.py --steps 1 --warmup 0 $QUIET > $R/gpurun_out/r02_pmcb_$c.log 2>&1
   python3 $R/tools/pmc_summary.py $R/gpurun_out/pmcb_$c "${KERNELS[@]}" > $R/gpurun_out/r02_pmc_$c.json

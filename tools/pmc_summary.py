@@ -10,7 +10,9 @@ for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"]
     if want and not any(w in name for w in want):
         continue
-    short = name.split("(")[0][-60:] if not want else next(w for w in want if w in name)
+    # without a filter: the kernel's name up to its parameter list (template arguments kept), last 90 characters
+    clean = name.replace("(anonymous namespace)::", "")
+    short = next(w for w in want if w in name) if want else (clean[:clean.rfind(">(") + 1] if ">(" in clean else clean.split("(")[0])[-90:]
     a = acc[(short, r["Counter_Name"])]
     a[0] += float(r["Counter_Value"]); a[1] += 1
 print(json.dumps({f"{k[0]}|{k[1]}": {"mean_per_launch": v[0] / v[1], "launches": v[1]} for k, v in acc.items()}, indent=1))

@@ -8,25 +8,45 @@ G = lambda n: os.path.join(R, "gpurun_out", n)
 P = lambda n: os.path.join(R, "profiles", n)
 TAG = "r02"
 fetch, write, mfma = (json.load(open(G(f"{TAG}_pmc_{c}.json"))) for c in ("FETCH_SIZE", "WRITE_SIZE", "mfma"))
-names = {"conv3x3_bf16x3": "Geo<3, 3, 1", "conv1x5_bf16x3": "Geo<1, 5, 1", "conv5x1_bf16x3": "Geo<5, 1, 1",
-         "conv3x3s2_bf16x3": "Geo<3, 3, 2", "conv1x1s2_bf16x3": "Geo<1, 1, 2", "conv7x7_bf16x3": "conv7_split_kernel",
-         "corr2d_bf16x3": "corr_abt_kernel<128", "corr1d_bf16x3": "corr_abt_kernel<160", "pyr2d": "pyramid2d", "pyr1d": "pyramid1d",
-         "lookup2d": "lookup2d", "lookup1d": "lookup1d", "instnorm_apply": "instnorm_apply_kernel", "conv1x1": "conv1x1_kernel"}
+import re
+# entry point -> pattern over the kernels' templated names (GRU stores are the instantiations whose last argument is true)
+names = {"conv3x3_bf16x3": r"Geo<3, 3, 1, 4, (32|16)>, (true|false), [12], false>", "conv5_bf16x3": r"Geo<(1, 5|5, 1), 1, 4, (32|16)>, (true|false), [12], false>",
+         "gru_conv_bf16x3": r"Geo<.*>, false, 2, true>", "conv3x3s2_bf16x3": r"Geo<3, 3, 2", "conv1x1s2_bf16x3": r"Geo<1, 1, 2",
+         "conv1x1_bf16x3": r"Geo<1, 1, 1", "conv7x7_bf16x3": r"conv7_split_kernel", "corr2d_bf16x3": r"corr_abt_kernel<128",
+         "corr1d_bf16x3": r"corr_abt_kernel<160", "pyr2d": r"pyramid2d", "pyr1d": r"pyramid1d", "lookup2d": r"lookup2d", "lookup1d": r"lookup1d",
+         "instnorm_apply": r"instnorm_apply_kernel", "conv1x1": r"conv1x1_kernel"}
+
+
+def grouped(table, pattern, counter):
+    """Launch-weighted mean of `counter` over the kernels whose name matches `pattern`."""
+    tot, n = 0.0, 0
+    for key, v in table.items():
+        name, c = key.rsplit("|", 1)
+        if c == counter and re.search(pattern, name):
+            tot += v["mean_per_launch"] * v["launches"]; n += v["launches"]
+    return (tot / n, n) if n else (None, 0)
+
+
 traffic = {"batch_pairs": 192, "height": 480, "width": 640,
            "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0` "
-                   "(tools/collect_profiles_r02.sh): the first chunk (193 stereo frames) and one steady step, mean per launch "
-                   "over every launch of the kernel (all layer shapes). Values in KiB as reported. On gfx950 FETCH_SIZE counts "
-                   "64 B per 128-B fabric read request, so wide streaming reads show half their bytes: read bytes ~= 2 x FETCH_SIZE; "
-                   "WRITE_SIZE is exact.", "kernels": {}}
+                   "(tools/collect_profiles_r02.sh): the first chunk (193 stereo frames) and one steady step, launch-weighted mean "
+                   "over every launch of the entry point's kernels (all layer shapes). Values in KiB as reported. On gfx950 FETCH_SIZE "
+                   "counts 64 B per 128-B fabric read request of a wide streaming read, so such reads show half their bytes: read bytes "
+                   "~= 2 x FETCH_SIZE; gathered reads (the lookups) are counted per touched 128-byte line without that halving "
+                   "(profiles/r02_lookup_layouts.txt); WRITE_SIZE is exact.", "kernels": {}}
 util = {"batch_pairs": 192, "height": 480, "width": 640,
-        "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), means per launch over the same run "
-                "(all layer shapes of a kernel together)", "kernels": {}}
-for key, sub in names.items():
-    f, w = fetch.get(sub + "|FETCH_SIZE"), write.get(sub + "|WRITE_SIZE")
-    if f and w:
-        traffic["kernels"][key] = {"FETCH_SIZE_KiB_per_launch": f["mean_per_launch"], "launches_fetch": f["launches"],
-                                   "WRITE_SIZE_KiB_per_launch": w["mean_per_launch"], "launches_write": w["launches"]}
-    c = {k.split("|")[1]: v["mean_per_launch"] for k, v in mfma.items() if k.startswith(sub + "|")}
+        "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), launch-weighted means over the same run "
+                "(all layer shapes of an entry point together)", "kernels": {}}
+for key, pat in names.items():
+    f, nf = grouped(fetch, pat, "FETCH_SIZE")
+    w, nw = grouped(write, pat, "WRITE_SIZE")
+    if nf and nw:
+        traffic["kernels"][key] = {"FETCH_SIZE_KiB_per_launch": f, "launches_fetch": nf, "WRITE_SIZE_KiB_per_launch": w, "launches_write": nw}
+    c = {}
+    for counter in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
+        v, n = grouped(mfma, pat, counter)
+        if n:
+            c[counter] = v; c["launches"] = n
     if c.get("GRBM_GUI_ACTIVE"):
         c["mfma_busy_frac"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * c["GRBM_GUI_ACTIVE"] / 8)
         util["kernels"][key] = c
