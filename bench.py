@@ -429,9 +429,11 @@ def main():
             "vs_baseline": None,
             "dtype": ("f16 activations, f32 weights/correlation/geometry" if args.mixed_precision else
                       ("f32" if args.conv_arithmetic == "f32" else
-                       "f32 (tensors, accumulation and every other operator in float32; the products of the 3x3, 1x5/5x1 and "
-                       "stride-2 3x3 convolutions are assembled from three bf16 matrix-core terms, 16 significant bits each, "
-                       "measured error below the float32 Winograd kernels' -- see f32_mfma_only for those)")),
+                       "f32 (tensors, accumulation and every other operator in float32; the products of the 3x3, 1x5/5x1, "
+                       "stride-2, many-channel 1x1 and one/two-channel 7x7 convolutions (GRU gate convolutions included) and of "
+                       "the correlation volumes are assembled from three bf16 matrix-core terms, 16 significant bits each, "
+                       "measured error below the float32 Winograd kernels' -- see f32_mfma_only for every product on the "
+                       "float32 matrix instruction)")),
             "data": "synthetic",
             "config": {"workload": f"RAFT-Flow + RAFT-Stereo({args.stereo} args) {W}x{H}, {args.iters} iters, "
                                    f"{n_kp} grid keypoints, {'Kabsch' if args.pose == 'svd' else 'RANSAC'} pose; "
