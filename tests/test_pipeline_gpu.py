@@ -30,8 +30,9 @@ def test_chunking_and_oracle_poses(vo):
     assert T_all.shape == (F - 1, 4, 4)
     ok = ~(sk_all | sk_chunks)
     assert torch.equal(sk_all, sk_chunks)
-    # batch size changes MIOpen's reduction order a little; poses stay within the north-star tolerance
-    assert (T_all[ok] - T_chunks[ok]).abs().max().item() < 1e-3
+    # the batch size changes the order of the plane statistics' atomic sums (and MIOpen's reductions on this small
+    # size) a little; poses stay a factor ten inside the north-star tolerance of 1e-3
+    assert (T_all[ok] - T_chunks[ok]).abs().max().item() < 1e-4
     # the geometry half against the NumPy oracle on the same maps
     depth = pipe.depth_maps(l, r)
     flow = pipe.flows(l)

@@ -679,6 +679,17 @@ def test_instance_norm_from_convolution_statistics(vo, tile):
         want = torch.relu(skip + torch.relu(Fn.instance_norm(ref_y.float(), eps=1e-5)))
         got = ops.instance_norm_apply_(y, stats, 1e-5, True, skip)
         assert (got - want).abs().max().item() < (5e-5 if tile == 2 else 3e-4)
+    # a plane whose mean is a hundred times its spread: the variance formed from the kernel's sums still matches
+    # the variance of the kernel's own output (cross-lane sums in float64)
+    x = (50.0 + 0.05 * _rand(1, 16, 64, 96, seed=93)).to(DEV)
+    w = (_rand(32, 16, 3, 3, seed=94).abs() / 50).to(DEV)
+    stats = torch.zeros((1, 32, 2), device=DEV, dtype=torch.float64)
+    full = ops.conv3x3_winograd(x, ops.winograd_filter(w, tile), 32, stats=stats).double()
+    hw = full.shape[2] * full.shape[3]
+    mean_k, var_k = stats[0, :, 0] / hw, stats[0, :, 1] / hw - (stats[0, :, 0] / hw) ** 2
+    mean_o, var_o = full.mean((2, 3))[0], full.var((2, 3), unbiased=False)[0]
+    assert (mean_k - mean_o).abs().max().item() < 1e-7 * mean_o.abs().max().item()
+    assert ((var_k - var_o).abs() / var_o).max().item() < 1e-3
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(x, U, K, None, skip[0, :, 0, 0].contiguous(), False, None, None, stats)
 

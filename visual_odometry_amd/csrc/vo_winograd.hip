@@ -284,11 +284,15 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
                     for (int c = 0; c < 4; ++c)
                         if (oy + r < H && ox + c < W) { ps += o[r][c]; pq += o[r][c] * o[r][c]; }
 #pragma unroll
-                for (int m2 = 16; m2 > 0; m2 >>= 1) { ps += __shfl_xor(ps, m2, VO_WAVE); pq += __shfl_xor(pq, m2, VO_WAVE); }
+                // float32 only over the lane's own few pixels; across lanes in float64, so that the variance
+                // E[x^2] - mean^2 formed from these sums survives planes whose mean dwarfs their spread
+                double dps = (double)ps, dpq = (double)pq;
+#pragma unroll
+                for (int m2 = 16; m2 > 0; m2 >>= 1) { dps += __shfl_xor(dps, m2, VO_WAVE); dpq += __shfl_xor(dpq, m2, VO_WAVE); }
                 if (tp == 0 && k < K) {
                     double* st = ep.stats + ((int64_t)n * K + k) * 2;
-                    atomicAdd(st, (double)ps);
-                    atomicAdd(st + 1, (double)pq);
+                    atomicAdd(st, dps);
+                    atomicAdd(st + 1, dpq);
                 }
             }
             if (k < K && oy < H && ox < W) {
