@@ -11,12 +11,15 @@
 // runs at the vector rate (1/16 of the bf16 rate), so three bf16 instructions per product are
 // still five times its throughput, and the direct form needs no transforms.
 //
-// One kernel template, three layer types: 3x3 stride 1 (padding 1), 1x5 / 5x1 stride 1 (padding
-// (0,2) / (2,0), the separable GRU's gates) and 3x3 stride 2 (padding 1, the encoders' downsampling).
+// One kernel template, several layer types: 3x3 stride 1 (padding 1), 1x5 / 5x1 stride 1 (padding
+// (0,2) / (2,0), the separable GRU's gates), 3x3 stride 2 (padding 1, the encoders' downsampling),
+// 1x1 stride 2 (their projection shortcuts) and 1x1 stride 1 with many channels; and the two
+// convolutions of a GRU step with the gate arithmetic in their stores (GruEp).
 //
 // Implicit GEMM: out[k, pixel] = sum over (tap, c) of W[k, c, tap] * x[c, stride*pixel + tap].
-//   workgroup = 4 waves: 64 (or 32) output channels x TH rows x 32 columns of one image
-//   wave w    = rows NTW*w .. NTW*w + NTW-1: MT x NTW accumulator tiles of 32 channels x 32 pixels
+//   workgroup = 4 waves: 64 (or 32) output channels x (16 rows x 32 columns | 32 rows x 16 columns) of one image
+//   wave w    = a quarter of the rows: MT x NTW accumulator tiles of 32 channels x 32 pixels (one row x 32
+//               columns, or two rows x 16 columns)
 //   input channels stream in chunks of 16 (one k-step): the patch of a chunk is split into high and
 //   low parts while it is staged and lies in LDS as [part][k-half][row][column][8 channels] (a lane's
 //   B fragment of any tap is one 16-byte read, lanes on consecutive 16-byte slots; with stride 2 the
