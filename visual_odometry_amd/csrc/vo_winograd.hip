@@ -283,7 +283,6 @@ __global__ __launch_bounds__(512) void wino_kernel(const float* __restrict__ x, 
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (oy + r < H && ox + c < W) { ps += o[r][c]; pq += o[r][c] * o[r][c]; }
-#pragma unroll
                 // float32 only over the lane's own few pixels; across lanes in float64, so that the variance
                 // E[x^2] - mean^2 formed from these sums survives planes whose mean dwarfs their spread
                 double dps = (double)ps, dpq = (double)pq;
