@@ -323,7 +323,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     const int col = x0 + pcol, lh = lane >> 5;
     const int row0 = y0 + NTW * G::PH * wave + prow;                         // this lane's row of pixel tile 0
 
-    if (ep.stats) {
+    // 16-byte store path (below): needs rows that keep 16-byte alignment; otherwise the accumulator layout is stored as it is
+    const bool wide = (Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ep.y_batch_stride & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(ep.skip) & 15) == 0;
+    if (ep.stats && !wide) {
         // plane sums of the raw output: per lane over its four rows, then over the 32 pixel lanes by a
         // halving exchange (each step hands half of the lane's channel rows to the partner lane and adds
         // the partner's half to its own), then over the four waves through LDS: one pair of float64
@@ -454,18 +457,19 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     // Wide path: every tile passes through a 4 KiB LDS slot of its wave (32 channels x 32 pixels), so that a
     // lane ends up with four consecutive pixels of one channel: 16-byte stores (and residual loads), a
     // quarter of the store instructions, each wave-instruction covering eight full 128-byte segments.
-    // Needs rows that keep 16-byte alignment; otherwise the accumulator layout is stored as it is.
-    const bool wide = (Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ep.y_batch_stride & 3) == 0 &&
-                      (reinterpret_cast<uintptr_t>(ep.skip) & 15) == 0;
+    // Plane sums ride along: a lane adds up the pixels it stores (float32 over its 16 pixels of a channel),
+    // the eight lanes that share a channel row combine in float64, the four waves through LDS.
     if (wide) {
-        if (ep.stats) __syncthreads();                                       // the reduction buffer lies in the same area
         float* slot = reinterpret_cast<float*>(lds) + wave * 1024;
+        double* redw = reinterpret_cast<double*>(lds + 4 * 4096);            // [2][4 waves][64], behind the four slots
+        static_assert(4 * PLANE + A_CHUNK >= 4 * 4096 + 2 * 4 * 64 * 8, "no room for the reduction buffer behind the slots");
         const int q = lane >> 3, px4 = (lane & 7) * 4;                       // read-back role: channel rows q + 8j, pixels px4..px4+3
         const int colw = x0 + px4 % G::TW, roww = y0 + NTW * G::PH * wave + px4 / G::TW;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             float sc[4], sh[4];
             int koff[4];
+            float w1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = kb * KB + mt * 32 + q + 8 * j;
@@ -491,6 +495,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 for (int j = 0; j < 4; ++j) {
                     const float4 t = *reinterpret_cast<const float4*>(slot + (q + 8 * j) * 32 + px4);
                     float v[4] = {t.x, t.y, t.z, t.w};
+                    if (ep.stats && pok) {                                   // rows are whole groups of four pixels: all in or all out
+                        w1[j] += (v[0] + v[1]) + (v[2] + v[3]);
+                        w2[j] = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], w2[j]))));
+                    }
                     u32x4 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -501,6 +509,28 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (pok && koff[j] >= 0) ? koff[j] + poff : (int)0x80000000, 0, 0);
                 }
+            }
+            if (ep.stats) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double d1 = (double)w1[j], d2 = (double)w2[j];
+#pragma unroll
+                    for (int m = 1; m < 8; m <<= 1) { d1 += __shfl_xor(d1, m, VO_WAVE); d2 += __shfl_xor(d2, m, VO_WAVE); }
+                    if ((lane & 7) == 0) {
+                        redw[(0 * 4 + wave) * 64 + mt * 32 + q + 8 * j] = d1;
+                        redw[(1 * 4 + wave) * 64 + mt * 32 + q + 8 * j] = d2;
+                    }
+                }
+            }
+        }
+        if (ep.stats) {
+            __syncthreads();
+            if (tid < 2 * 32 * MT) {
+                const int which = tid / (32 * MT), krow = tid - which * (32 * MT);
+                const double* rp = redw + which * 4 * 64 + krow;
+                const double tot = (rp[0] + rp[64]) + (rp[128] + rp[192]);
+                const int k = kb * KB + krow;
+                if (k < K) atomicAdd(ep.stats + ((int64_t)n * K + k) * 2 + which, tot);
             }
         }
         return;
