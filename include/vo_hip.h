@@ -197,6 +197,11 @@ int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, 
 int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
                       const float* scale, const float* shift, int relu,
                       int N, int C, int H, int W, int K, void* stream);
+/* vo_conv1x1_bf16x3 with y written pixel-major, (N, H*W, K) (K a multiple of 4): the feature encoders' last layer in the
+ * layout the correlation kernels read (cf. vo_conv1x1_pixel_major). */
+int vo_conv1x1_pixel_major_bf16x3(const float* x, const void* arranged, float* y,
+                                  const float* scale, const float* shift, int relu,
+                                  int N, int C, int H, int W, int K, void* stream);
 int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
                         int N, int C, int H, int W, int K, void* stream);

@@ -994,6 +994,10 @@ def test_split_bf16_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
     ref = torch.relu(want.float() + bias[None, :, None, None])
     assert (wide[:, 3:3 + K] - ref).abs().max().item() < 2 * tol
     assert torch.all(wide[:, :3] == 1.75) and torch.all(wide[:, 3 + K:] == 1.75)
+    # the same layer written pixel-major (N,H,W,K), the correlation kernels' input layout
+    pm = ops.conv1x1_pixel_major_split(x, A, K, None, bias, False)
+    assert pm.shape == (N, H, W, K)
+    assert (pm.permute(0, 3, 1, 2) - (want.float() + bias[None, :, None, None])).abs().max().item() < 2 * tol
     if C == 336:
         conv = torch.nn.Conv2d(324, K, 1).to(DEV).eval()
         xp = x.clone(); xp[:, 324:] = 0.0

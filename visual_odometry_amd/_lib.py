@@ -38,6 +38,7 @@ SIGNATURES = {
     "vo_conv3x3s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv1x1_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv1x1_pixel_major_bf16x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_conv7x7_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv7x7_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],

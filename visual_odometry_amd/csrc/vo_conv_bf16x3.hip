@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void filter_split_kernel(const float* __restri
     }
 }
 
-struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; double* stats; };
+struct Epilogue { const float* scale; const float* shift; const float* skip; int relu; int64_t y_batch_stride; double* stats; int pixel_major; };
 struct InputNorm { const double* stats; float eps; };
 
 // Gate arithmetic of a convolutional GRU in the convolution's store (hidden width C, a multiple of 64):
@@ -322,6 +322,39 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         const_cast<float*>(ep.skip ? ep.skip + (int64_t)n * K * Ho * Wo : x), 0, ep.skip ? K * HWo4 : 0, 0x00020000);
     const int col = x0 + pcol, lh = lane >> 5;
     const int row0 = y0 + NTW * G::PH * wave + prow;                         // this lane's row of pixel tile 0
+
+    if (ep.pixel_major) {
+        // y as (N, Ho*Wo, K): a lane's four consecutive channel rows of one pixel are one 16-byte store (K % 4 == 0);
+        // the layout the correlation kernels read their feature maps in
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(y + (int64_t)n * Ho * Wo * K, 0, Ho * Wo * K * 4, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int k = kb * KB + mt * 32 + 8 * g + 4 * lh;
+                float sc[4], sh[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sc[i] = 1.0f; sh[i] = 0.0f;
+                    if (ep.shift && k < K) { sc[i] = ep.scale ? ep.scale[k + i] : 1.0f; sh[i] = ep.shift[k + i]; }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int row = row0 + nt * G::PH;
+                    const bool ok = row < Ho && col < Wo && k < K;
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[mt][nt][4 * g + i];
+                        if (ep.shift) v = fmaf(v, sc[i], sh[i]);
+                        if (ep.relu) v = fmaxf(v, 0.0f);
+                        o[i] = __float_as_uint(v);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, prs, ok ? ((row * Wo + col) * K + k) * 4 : (int)0x80000000, 0, 0);
+                }
+            }
+        return;
+    }
 
     // 16-byte store path (below): needs rows that keep 16-byte alignment; otherwise the accumulator layout is stored as it is
     const bool wide = (Wo & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ep.y_batch_stride & 3) == 0 &&
@@ -591,8 +624,10 @@ int split_filter(const char* name, const float* weight, void* arranged, int K, i
 template <typename G>
 int launch_conv(const char* name, const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
                 const float* shift, int relu, const float* skip, double* stats, const double* in_stats, float in_eps, int N,
-                int C, int H, int W, int K, hipStream_t st) {
+                int C, int H, int W, int K, hipStream_t st, bool pixel_major = false) {
     if (!x || !arranged || !y) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if (pixel_major && (K % 4 != 0 || skip || stats || (reinterpret_cast<uintptr_t>(y) & 15) != 0))
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: the pixel-major store needs K %% 4 == 0, a 16-byte aligned output, no skip, no statistics", name);
     if (scale && !shift) return vo_fail(VO_ERR_INVALID_ARG, "%s: scale without shift", name);
     if (stats && (shift || relu || skip))
         return vo_fail(VO_ERR_INVALID_ARG, "%s: statistics are of the raw output, no epilogue with them", name);
@@ -606,13 +641,14 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
         return vo_fail(VO_ERR_UNSUPPORTED, "%s: needs an even width and an 8-byte aligned input (W=%d)", name, W);
     if ((int64_t)C * H * W * 4 >= 0x7fffffffLL || (int64_t)K * Ho * Wo * 4 >= 0x7fffffffLL)
         return vo_fail(VO_ERR_UNSUPPORTED, "%s: one image of the input or output exceeds 2 GiB", name);
+    if (pixel_major) y_batch_stride = (int64_t)K * Ho * Wo;
     if (in_stats && C > G::MAX_NORM_C)
         return vo_fail(VO_ERR_UNSUPPORTED, "%s: normalise-on-load supports at most %d input channels", name, G::MAX_NORM_C);
     const int bx = (Wo + G::TW - 1) / G::TW, by = (Ho + G::TH - 1) / G::TH;
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
-    const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats};
+    const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats, pixel_major ? 1 : 0};
     const InputNorm nrm{in_stats, in_eps};
     const unsigned short* ag = static_cast<const unsigned short*>(arranged);
     // a last block with at most 32 channels goes out as a launch of its own with one channel tile --
@@ -661,7 +697,7 @@ int launch_gru(const char* name, const float* x, const unsigned short* ag, float
     const int bx = (W + G::TW - 1) / G::TW, by = (H + G::TH - 1) / G::TH, kblocks = K / KB;
     const int64_t blocks = (int64_t)bx * by * N * kblocks;
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
-    const Epilogue ep{nullptr, shift, nullptr, 0, y_batch_stride, nullptr};
+    const Epilogue ep{nullptr, shift, nullptr, 0, y_batch_stride, nullptr, 0};
     conv_bf16x3_kernel<G, false, 2, true><<<dim3((unsigned)blocks), dim3(NT), 0, st>>>(x, ag, y, ep, InputNorm{nullptr, 0.0f}, C, H, W, H, W, K,
                                                                                      bx, by, kblocks, 0, gru);
     hipError_t e = hipGetLastError();
@@ -771,4 +807,13 @@ extern "C" int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y,
                                     0.0f, N, C, H, W, K, vo_stream(stream));
     return launch_conv<Geo1x1>("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr, 0.0f,
                                N, C, H, W, K, vo_stream(stream));
+}
+
+extern "C" int vo_conv1x1_pixel_major_bf16x3(const float* x, const void* arranged, float* y, const float* scale, const float* shift,
+                                             int relu, int N, int C, int H, int W, int K, void* stream) {
+    if (narrow_blocks_fit_better(H, W))
+        return launch_conv<Geo1x1n>("vo_conv1x1_pixel_major_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, nullptr, nullptr,
+                                    0.0f, N, C, H, W, K, vo_stream(stream), true);
+    return launch_conv<Geo1x1>("vo_conv1x1_pixel_major_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, nullptr, nullptr, 0.0f,
+                               N, C, H, W, K, vo_stream(stream), true);
 }

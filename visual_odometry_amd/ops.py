@@ -426,6 +426,24 @@ def conv1x1_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.
     return out
 
 
+def conv1x1_pixel_major_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
+                              shift: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
+    """conv1x1_split with the output in pixel-major order: x (N,C,H,W) float32 -> (N,H,W,K), K a multiple of 4."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C or K % 4:
+        raise ValueError("arranged weights do not match (K, C), K a multiple of 4")
+    if W % 2:
+        raise ValueError("the split-bf16 kernel needs an even width")
+    for t, name in ((scale, "scale"), (shift, "shift")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    out = torch.empty((N, H, W, K), device=x.device, dtype=torch.float32)
+    _call("vo_conv1x1_pixel_major_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
+          nbytes=4 * (x.numel() + out.numel()), flops=2 * 3 * N * K * C * H * W)
+    return out
+
+
 def conv1x1s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
                     shift: torch.Tensor | None = None, relu: bool = False, stats: torch.Tensor | None = None) -> torch.Tensor:
     """conv2d(x, weight(K,C,1,1), stride=2) on the split-bf16 direct kernel (weights from

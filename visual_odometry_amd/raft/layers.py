@@ -104,6 +104,10 @@ def conv_pixel_major(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     the correlation kernels read.  A float32 1x1 convolution writes it directly; anything else is
     the convolution followed by the permuting copy."""
     if (x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and fused_on() and conv.bias is not None and x.is_cuda):
+        if conv.out_channels % 4 == 0 and x.is_contiguous():
+            Ws = _conv1x1_split_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Ws is not None:
+                return ops.conv1x1_pixel_major_split(x, Ws, conv.out_channels, None, conv.bias, False)
         Wg = _conv1x1_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
         if Wg is not None:
             return ops.conv1x1_pixel_major(x, Wg, conv.out_channels, None, conv.bias, False)
