@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel time of ONE steady-state bench step from a rocprofv3 kernel trace
-(rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py ...)."""
-import collections, csv, glob, sys
+(rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py ...), and the same time grouped by
+the C-ABI entry point the kernels belong to (an entry point may launch two kernels: full 64-channel blocks
+and a last block of at most 32 channels)."""
+import collections, csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -17,3 +19,17 @@ print(f"step wall {(t1 - t0) / 1e6:.2f} ms, busy {tot / 1e6:.2f} ms, {len(seg)} 
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 for n, v in d.most_common(top):
     print(f"{v / 1e6:8.2f} ms {100 * v / tot:5.1f}% x{c[n]:4d}  {n}")
+
+groups = [("vo_conv3x3_bf16x3", r"conv_bf16x3_kernel<.*Geo<3, 3, 1, 4, (32|16)>, (true|false), [12], false>"),
+          ("vo_gru_conv_zr/q_bf16x3", r"conv_bf16x3_kernel<.*Geo<.*>, false, 2, true>"),
+          ("vo_conv5_bf16x3", r"conv_bf16x3_kernel<.*Geo<(1, 5|5, 1), 1, 4, (32|16)>, (true|false), [12], false>"),
+          ("vo_conv3x3s2_bf16x3", r"conv_bf16x3_kernel<.*Geo<3, 3, 2"), ("vo_conv1x1s2_bf16x3", r"conv_bf16x3_kernel<.*Geo<1, 1, 2"),
+          ("vo_conv1x1[_pixel_major]_bf16x3", r"conv_bf16x3_kernel<.*Geo<1, 1, 1"), ("vo_conv7x7_bf16x3", r"conv7_split_kernel"),
+          ("vo_conv1x1 / _pixel_major / taps", r"conv1x1_kernel"), ("vo_instance_norm_apply", r"instnorm_apply_kernel"),
+          ("vo_corr_volume_2d_bf16x3", r"corr_abt_kernel<128"), ("vo_corr_volume_1d_bf16x3", r"corr_abt_kernel<160"),
+          ("vo_corr_pyramid_2d", r"pyramid2d_kernel"), ("vo_corr_lookup_2d", r"lookup2d_kernel"), ("vo_corr_lookup_1d", r"lookup1d_kernel")]
+print("\nby entry point (kernel launches of one step; a call with a last block of <= 32 channels launches two kernels):")
+for name, pat in groups:
+    sel = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg if re.search(pat, r["Kernel_Name"])]
+    if sel:
+        print(f"{sum(sel) / 1e6:8.2f} ms {100 * sum(sel) / tot:5.1f}%  {len(sel):4d} kernel launches  {name}")
