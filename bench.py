@@ -42,7 +42,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak
 # kernels whose float32 products are three bf16 matrix-core terms: their recorded FLOPs are the bf16
 # multiply-adds they issue (three per product), priced against the bf16 peak
 SPLIT_BF16_KERNELS = ("vo_conv3x3_bf16x3", "vo_conv5_bf16x3", "vo_conv3x3s2_bf16x3", "vo_conv1x1s2_bf16x3", "vo_conv7x7_bf16x3",
-                      "vo_corr_volume_2d_bf16x3", "vo_corr_volume_1d_bf16x3")
+                      "vo_corr_volume_2d_bf16x3", "vo_corr_volume_1d_bf16x3", "vo_corr_volume_2d_presplit")
 
 
 def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256):
@@ -62,6 +62,8 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
         "vo_corr_volume_2d_bf16x3": dict(launches=1, flops=6.0 * n * n * D * B, bytes=(2 * n * D + n * n) * f * B),
         "vo_corr_volume_1d_bf16x3": dict(launches=1, flops=6.0 * h4 * w4 * w4 * D * B,
                                          bytes=(2 * h4 * w4 * D + h4 * w4 * w4) * f * B),
+        # the same volume from feature rows split beforehand (the flow network's default under the split arithmetic)
+        "vo_corr_volume_2d_presplit": dict(launches=1, flops=6.0 * n * n * D * B, bytes=(2 * n * D + n * n) * f * B),
         "vo_corr_pyramid_2d": dict(launches=1, bytes=B * n * sum(lv2) * f),
         "vo_corr_pyramid_1d": dict(launches=1, bytes=B * h4 * w4 * sum(lv1) * f),
         # coords + window out + the (2r+2)^2 patch each pixel needs per level
@@ -79,6 +81,7 @@ PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_co
             "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4", "vo_conv5_winograd": "winograd1d",
             "vo_conv3x3_bf16x3": "conv3x3_bf16x3", "vo_conv3x3s2_bf16x3": "conv3x3s2_bf16x3", "vo_conv7x7_bf16x3": "conv7x7_bf16x3",
             "vo_corr_volume_2d_bf16x3": "corr2d_bf16x3", "vo_corr_volume_1d_bf16x3": "corr1d_bf16x3",
+            "vo_corr_volume_2d_presplit": "corr2d_presplit",
             "vo_instance_norm_apply": "instnorm_apply", "vo_conv1x1": "conv1x1"}
 
 
@@ -418,6 +421,18 @@ def main():
                          "traffic": pmc_traffic("vo_corr_volume_2d_bf16x3", B, H, W),
                          "note": "split-bf16 products (three bf16 matrix-core terms per float32 product); the float32-instruction "
                                  "kernel's figures are in the f32_mfma_only leg's run (--conv-arithmetic f32)"}
+    cp = kernels.get("vo_corr_volume_2d_presplit")
+    if cp:
+        # rows split beforehand, 256 x 256 tiles: the matrix instructions (three per product) are the larger floor
+        # (0.91 ms per 64 pairs at the bf16 peak against 0.77 ms for the volume's bytes at the HBM peak)
+        roofline_corr = {"kernel": "vo_corr_volume_2d_presplit", "bound": "mfma", "achieved": cp["TFLOPs"], "peak": BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": cp["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS, "avg_launch_us": cp["avg_us"],
+                         "float32_equivalent_TFLOPs": cp["TFLOPs"] / 3.0, "hbm_GBps": cp["GBps"],
+                         "hbm_frac": cp["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic("vo_corr_volume_2d_presplit", B, H, W),
+                         "mfma_busy_pmc": mfma_util_from_profile("corr2d_presplit", B, H, W),
+                         "note": "split-bf16 products (three bf16 matrix-core terms per float32 product) on feature rows split into "
+                                 "their bf16 pieces by the encoder's last layer; achieved counts the bf16 multiply-adds issued; "
+                                 "the float32-instruction kernel's figures are in the f32_mfma_only leg's run (--conv-arithmetic f32)"}
     roofline["alg_per_launch"] = (work[dom].get("flops") if roofline["bound"] == "mfma" else work[dom]["bytes"]) / work[dom]["launches"]
     hand_ms = sum(k["ms_per_step"] for k in kernels.values())
 

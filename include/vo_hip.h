@@ -202,6 +202,11 @@ int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_
 int vo_conv1x1_pixel_major_bf16x3(const float* x, const void* arranged, float* y,
                                   const float* scale, const float* shift, int relu,
                                   int N, int C, int H, int W, int K, void* stream);
+/* vo_conv1x1_pixel_major_bf16x3 whose rows leave as bf16 pieces in blocks of 32 channels (K a multiple of 32): the
+ * input form of vo_corr_volume_2d_presplit, see vo_split_feature_rows.  y holds N*H*W*K*4 bytes. */
+int vo_conv1x1_split_rows_bf16x3(const float* x, const void* arranged, void* y,
+                                 const float* scale, const float* shift, int relu,
+                                 int N, int C, int H, int W, int K, void* stream);
 int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
                         int N, int C, int H, int W, int K, void* stream);
@@ -344,6 +349,19 @@ int vo_corr_volume_2d_bf16x3(const float* fmap1, const float* fmap2, float* corr
                              int batch, int H, int W, int D, void* stream);
 int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, float* corr,
                              int batch, int H, int W1, int W2, int D, void* stream);
+/* ... and on feature maps whose rows were split into those bf16 pieces beforehand, once per map instead of once per
+ * tile that reads the row (the call sites are the same: flow/flow_map_RAFT.py:81, stereo/stereo_disparity_RAFT.py:91).
+ * vo_split_feature_rows turns `rows` rows of D float32 into the same 4*D bytes per row: per block of `block`
+ * features (32 for the 2-D volume, 16 for the 1-D one; D a multiple of it), `block` high parts (bf16(x)) followed by
+ * `block` low parts (bf16(x - high)); out must not alias x.  vo_conv1x1_split_rows_bf16x3 (above) writes the
+ * block-32 form from a feature encoder's last layer directly.  Results equal vo_corr_volume_*_bf16x3 bit for bit.
+ * The 2-D kernel: 256 x 256 tiles, one workgroup per CU walking a tile list, the next tile's first slices requested
+ * before the finished tile is stored. */
+int vo_split_feature_rows(const float* x, void* out, int64_t rows, int D, int block, void* stream);
+int vo_corr_volume_2d_presplit(const void* fmap1, const void* fmap2, float* corr,
+                               int batch, int H, int W, int D, void* stream);
+int vo_corr_volume_1d_presplit(const void* fmap1, const void* fmap2, float* corr,
+                               int batch, int H, int W1, int W2, int D, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Correlation pyramid: levels 1..3 from level 0 in one pass (avg_pool 2x2 / 1x2,

@@ -84,6 +84,61 @@ def test_corr_volume_1d(vo, B, H, W, D, split):
     assert (got.cpu() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
 
 
+def _split_rows_host(x: torch.Tensor, block: int) -> torch.Tensor:
+    """Host statement of the split-row format: per row and block of ``block`` features, ``block`` high parts
+    (bfloat16(x), round to nearest even) then ``block`` low parts (bfloat16(x - high)); returned as int16 bits
+    (..., 2*D)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    D = x.shape[-1]
+    hb = hi.view(torch.int16).reshape(*x.shape[:-1], D // block, block)
+    lb = lo.view(torch.int16).reshape(*x.shape[:-1], D // block, block)
+    return torch.cat([hb, lb], dim=-1).reshape(*x.shape[:-1], 2 * D)
+
+
+@pytest.mark.parametrize("B,H,W,D", [(2, 12, 20, 256), (1, 7, 10, 64), (1, 9, 65, 256), (1, 60, 80, 256), (3, 33, 40, 128)])
+def test_corr_volume_2d_on_rows_split_beforehand(vo, B, H, W, D):
+    """vo_split_feature_rows against the host statement of its format (bit for bit), and the volume kernel
+    for such rows (256 x 256 tiles, persistent workgroups; maps smaller and larger than a tile, partial
+    tiles, several tiles per workgroup) against the kernel that splits inside (bit for bit: the same
+    products in the same order) and against the float64 restatement."""
+    from visual_odometry_amd import ops
+    f1, f2 = _rand(B, H, W, D, seed=21).to(DEV), _rand(B, H, W, D, seed=22).to(DEV)
+    s1, s2 = ops.split_feature_rows(f1, 32), ops.split_feature_rows(f2, 32)
+    assert torch.equal(s1.view(torch.int16).cpu(), _split_rows_host(f1.cpu(), 32))
+    got = ops.corr_volume_2d_presplit(s1, s2)
+    assert torch.equal(got, ops.corr_volume_2d(f1, f2, split=True))
+    want = raft_ref.corr_volume_2d(_nchw(f1.cpu()).double(), _nchw(f2.cpu()).double()).float()
+    assert (got.cpu() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.equal(got, ops.corr_volume_2d_presplit(s1, s2))
+
+
+def test_corr_volume_presplit_exact_on_integers_and_1d(vo):
+    """Small integers make every product exact (see test_corr_volume_exact_on_integers): a slip in the row
+    format, the tile list or the store path shows as a wrong integer.  Sizes: 585 and 1300 pixels (three and
+    six 256-tiles per side, the last partial), and the 1-D flavour on blocks of 16."""
+    from visual_odometry_amd import ops
+    g = torch.Generator().manual_seed(23)
+    for (H, W) in ((9, 65), (26, 50)):
+        f1 = torch.randint(-3, 4, (2, H, W, 256), generator=g).float()
+        f2 = torch.randint(-3, 4, (2, H, W, 256), generator=g).float()
+        got = ops.corr_volume_2d_presplit(ops.split_feature_rows(f1.to(DEV), 32), ops.split_feature_rows(f2.to(DEV), 32))
+        want = (torch.einsum("bid,bjd->bij", f1.view(2, H * W, 256).double(), f2.view(2, H * W, 256).double()) / 16.0).float()
+        assert torch.equal(got.cpu().view(2, H * W, H * W), want)
+    f1 = torch.randint(-3, 4, (2, 5, 50, 64), generator=g).float()
+    f2 = torch.randint(-3, 4, (2, 5, 37, 64), generator=g).float()
+    r1, r2 = ops.split_feature_rows(f1.to(DEV), 16), ops.split_feature_rows(f2.to(DEV), 16)
+    assert torch.equal(r1.view(torch.int16).cpu(), _split_rows_host(f1, 16))
+    got = ops.corr_volume_1d_presplit(r1, r2).cpu()
+    want = (torch.einsum("bhid,bhjd->bhij", f1.double(), f2.double()) / 8.0).float()
+    assert got.shape == (2, 5, 50, 37) and torch.equal(got, want)
+    h1, h2 = _rand(2, 6, 160, 256, seed=24).to(DEV), _rand(2, 6, 160, 256, seed=25).to(DEV)
+    assert torch.equal(ops.corr_volume_1d_presplit(ops.split_feature_rows(h1, 16), ops.split_feature_rows(h2, 16)),
+                       ops.corr_volume_1d(h1, h2, split=True))
+    with pytest.raises(ValueError):
+        ops.split_feature_rows(torch.zeros(4, 48, device=DEV), 32)              # D not a multiple of the block
+
+
 def test_corr_rejects_bad_input(vo):
     from visual_odometry_amd import ops
     from visual_odometry_amd._lib import VoHipError
@@ -998,6 +1053,10 @@ def test_split_bf16_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
     pm = ops.conv1x1_pixel_major_split(x, A, K, None, bias, False)
     assert pm.shape == (N, H, W, K)
     assert (pm.permute(0, 3, 1, 2) - (want.float() + bias[None, :, None, None])).abs().max().item() < 2 * tol
+    if K % 32 == 0:
+        # ... and with its rows leaving as bf16 pieces: the bits of vo_split_feature_rows over the float32 rows
+        sr = ops.conv1x1_pixel_major_split(x, A, K, None, bias, False, split_rows=True)
+        assert torch.equal(sr.view(torch.int16), ops.split_feature_rows(pm, 32).view(torch.int16))
     if C == 336:
         conv = torch.nn.Conv2d(324, K, 1).to(DEV).eval()
         xp = x.clone(); xp[:, 324:] = 0.0

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vo_conv1x1_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv1x1_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_pixel_major_bf16x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv1x1_split_rows_bf16x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_conv7x7_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv7x7_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -63,6 +64,9 @@ SIGNATURES = {
     "vo_corr_volume_1d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_corr_volume_2d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_1d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vo_split_feature_rows": [_P, _P, _L, _I, _I, _P],
+    "vo_corr_volume_2d_presplit": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vo_corr_volume_1d_presplit": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_tile_feature_rows": [_P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_mn": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vo_corr_pyramid_2d_tiled": [_P, _P, _P, _P, _L, _I, _I, _P],

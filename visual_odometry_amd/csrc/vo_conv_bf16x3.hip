@@ -342,15 +342,28 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int row = row0 + nt * G::PH;
                     const bool ok = row < Ho && col < Wo && k < K;
-                    u32x4 o;
+                    float o[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float v = acc[mt][nt][4 * g + i];
                         if (ep.shift) v = fmaf(v, sc[i], sh[i]);
                         if (ep.relu) v = fmaxf(v, 0.0f);
-                        o[i] = __float_as_uint(v);
+                        o[i] = v;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(o, prs, ok ? ((row * Wo + col) * K + k) * 4 : (int)0x80000000, 0, 0);
+                    const int base = ok ? (row * Wo + col) * K * 4 : (int)0x80000000;
+                    if (ep.pixel_major == 2) {
+                        // the row as bf16 pieces in blocks of 32 channels, [32 high parts | 32 low parts] each:
+                        // what the correlation kernel for rows split beforehand reads
+                        const unsigned h0 = pack_bf16(o[0], o[1]), h1 = pack_bf16(o[2], o[3]);
+                        const unsigned l0 = pack_bf16(o[0] - __uint_as_float(h0 << 16), o[1] - __uint_as_float(h0 & 0xffff0000u));
+                        const unsigned l1 = pack_bf16(o[2] - __uint_as_float(h1 << 16), o[3] - __uint_as_float(h1 & 0xffff0000u));
+                        const int off = base + (k >> 5) * 128 + (k & 31) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, prs, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, prs, off + 64, 0, 0);
+                    } else {
+                        const u32x4 ov = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, prs, base + k * 4, 0, 0);
+                    }
                 }
             }
         return;
@@ -624,10 +637,11 @@ int split_filter(const char* name, const float* weight, void* arranged, int K, i
 template <typename G>
 int launch_conv(const char* name, const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
                 const float* shift, int relu, const float* skip, double* stats, const double* in_stats, float in_eps, int N,
-                int C, int H, int W, int K, hipStream_t st, bool pixel_major = false) {
+                int C, int H, int W, int K, hipStream_t st, int pixel_major = 0) {
     if (!x || !arranged || !y) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
     if (pixel_major && (K % 4 != 0 || skip || stats || (reinterpret_cast<uintptr_t>(y) & 15) != 0))
         return vo_fail(VO_ERR_UNSUPPORTED, "%s: the pixel-major store needs K %% 4 == 0, a 16-byte aligned output, no skip, no statistics", name);
+    if (pixel_major == 2 && K % 32 != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: rows split in blocks of 32 need K %% 32 == 0 (K=%d)", name, K);
     if (scale && !shift) return vo_fail(VO_ERR_INVALID_ARG, "%s: scale without shift", name);
     if (stats && (shift || relu || skip))
         return vo_fail(VO_ERR_INVALID_ARG, "%s: statistics are of the raw output, no epilogue with them", name);
@@ -648,7 +662,7 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
     const int64_t blocks = (int64_t)bx * by * N;
     const int kblocks = (K + KB - 1) / KB;
     if (blocks * kblocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
-    const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats, pixel_major ? 1 : 0};
+    const Epilogue ep{scale, shift, skip, relu, y_batch_stride, stats, pixel_major};
     const InputNorm nrm{in_stats, in_eps};
     const unsigned short* ag = static_cast<const unsigned short*>(arranged);
     // a last block with at most 32 channels goes out as a launch of its own with one channel tile --
@@ -813,7 +827,17 @@ extern "C" int vo_conv1x1_pixel_major_bf16x3(const float* x, const void* arrange
                                              int relu, int N, int C, int H, int W, int K, void* stream) {
     if (narrow_blocks_fit_better(H, W))
         return launch_conv<Geo1x1n>("vo_conv1x1_pixel_major_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, nullptr, nullptr,
-                                    0.0f, N, C, H, W, K, vo_stream(stream), true);
+                                    0.0f, N, C, H, W, K, vo_stream(stream), 1);
     return launch_conv<Geo1x1>("vo_conv1x1_pixel_major_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, nullptr, nullptr, 0.0f,
-                               N, C, H, W, K, vo_stream(stream), true);
+                               N, C, H, W, K, vo_stream(stream), 1);
+}
+
+extern "C" int vo_conv1x1_split_rows_bf16x3(const float* x, const void* arranged, void* y, const float* scale, const float* shift,
+                                            int relu, int N, int C, int H, int W, int K, void* stream) {
+    float* out = static_cast<float*>(y);
+    if (narrow_blocks_fit_better(H, W))
+        return launch_conv<Geo1x1n>("vo_conv1x1_split_rows_bf16x3", x, arranged, out, 0, scale, shift, relu, nullptr, nullptr, nullptr,
+                                    0.0f, N, C, H, W, K, vo_stream(stream), 2);
+    return launch_conv<Geo1x1>("vo_conv1x1_split_rows_bf16x3", x, arranged, out, 0, scale, shift, relu, nullptr, nullptr, nullptr, 0.0f,
+                               N, C, H, W, K, vo_stream(stream), 2);
 }

@@ -25,12 +25,15 @@
 // the matrix cores to the store of the volume.
 #include "vo_common.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PAD = 4;   // floats of row padding in LDS
 
@@ -49,8 +52,8 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + (bid >> 3);
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void corr_abt_kernel(
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT, bool PRE = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N >= 8 ? 1 : 2) void corr_abt_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
     int64_t strideA, int64_t strideB, int64_t strideC, int tiles_m, int tiles_n, unsigned nwg, float divisor) {
     constexpr int THREADS = 64 * WAVES_M * WAVES_N;
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void corr_abt_kernel(
     static_assert((BM * BK / 4) % THREADS == 0 && (BN * BK / 4) % THREADS == 0, "staging mismatch");
     static_assert(BK % 8 == 0, "BK must be a multiple of 8");
     static_assert(!SPLIT || BK % 16 == 0, "the bf16 instruction takes 16 k per step");
+    static_assert(!PRE || SPLIT, "pre-split rows feed the bf16 instruction");
     // SPLIT: a row holds BK high parts then BK low parts (2 bytes each, as many bytes as BK floats); the
     // same padding keeps the 16-byte fragment reads of 32 consecutive rows on distinct banks
 
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void corr_abt_kernel(
     // four consecutive k of one row: as they are, or as four high parts (8 bytes at 2*k) and four low
     // parts (8 bytes at 2*BK + 2*k)
     auto store_f4 = [](float* row, int q, float4 v) {
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && !PRE) {
             const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
             const unsigned l0 = pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
             const unsigned l1 = pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
@@ -226,6 +230,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void corr_abt_kernel(
 
     const float inv_divisor = 1.0f / divisor;                    // SPLIT: no bit-for-bit claim to keep, one multiplication
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(Cg) & 15) == 0) {
+        // Every tile passes through a 4 KiB LDS slot of its wave, after which a lane holds four consecutive
+        // columns of one row: 16-byte stores, eight lanes per 128-byte segment, a quarter of the store
+        // instructions (the kernel's bound is the store of the volume).
+        __syncthreads();                                         // every wave is done with the operand tiles
+        float* slot = smem + wave * 1024;
+        const int q = lane >> 3, px4 = (lane & 7) * 4;
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    slot[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + lr] = SPLIT ? acc[m][n][e] * inv_divisor : acc[m][n][e] / divisor;
+                const int col = col0 + (wn * TN + n) * 32 + px4;
+                const int rbase = row0 + (wm * TM + m) * 32 + q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(slot + (q + 8 * j) * 32 + px4);
+                    const int row = rbase + 8 * j;
+                    if (row < M && col < N) {
+                        f32x4* dst = reinterpret_cast<f32x4*>(Cg + (int64_t)row * N + col);
+                        *dst = t;
+                    }
+                }
+            }
+        return;
+    }
     // Per register the two wave halves each write 32 consecutive floats of one row.
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -241,14 +273,209 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void corr_abt_kernel(
         }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT>
+// The large volume on rows split beforehand (blocks of 32 k): 256 x 256 tile, 8 waves of 64 rows x 128
+// columns, one workgroup per CU walking a list of tiles.
+//   * a wave reads 12 fragments per 24 matrix instructions (each A fragment feeds four column tiles, each B
+//     fragment two row tiles), fetched one (k-step, column tile) step ahead of their use;
+//   * K-slices of 32: one slice ahead in registers, two LDS buffers, one barrier per slice;
+//   * the first slice of the NEXT tile is requested during the last slice of the current one, so its memory
+//     latency passes under the matrix instructions and the store of the finished tile;
+//   * every 32 x 32 block goes through a 4 KiB LDS slot of its wave: 16-byte stores of whole 128-byte segments.
+constexpr int BIG = 256, BIG_ROWB = (32 + PAD) * 4, BIG_BUF = 2 * BIG * BIG_ROWB;
+__global__ __launch_bounds__(512, 1) void corr_presplit_big_kernel(
+    const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+    int64_t strideA, int64_t strideB, int64_t strideC, int tiles_m, int tiles_n, unsigned nwork, float inv_divisor) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_big[];      // [2][A rows | B rows][BIG_ROWB]
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int GROUP_M = 8;
+    const int rowb = K * 4;                                          // bytes of one feature row
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+
+    // Work list: one contiguous range per XCD (workgroups are dealt round robin over the 8 XCDs), the
+    // workgroups of an XCD taking its items in turn, so that at any time they work on neighbouring tiles.
+    const unsigned xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;              // the host launches a multiple of 8
+    const unsigned q8 = nwork >> 3, r8 = nwork & 7u;
+    const unsigned range0 = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned range1 = range0 + q8 + (xcd < r8 ? 1u : 0u);
+
+    int g, row0, col0;
+    int goff_a[4], goff_b[4], loff[4];
+    __amdgpu_buffer_rsrc_t ars, brs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 512;
+        loff[i] = (f >> 3) * BIG_ROWB + (f & 7) * 16;
+    }
+    // the tile of work item w: row tiles in groups of GROUP_M, a group sweeping the column tiles with the
+    // row tile fastest (neighbouring items share B tiles and a few A tiles through L2)
+    auto setup = [&](unsigned w) {
+        const unsigned per_g = (unsigned)tiles_n * tiles_m;
+        g = w / per_g;
+        const unsigned w_in = w - g * per_g;
+        const unsigned group_sz = GROUP_M * tiles_n;
+        const unsigned grp = w_in / group_sz;
+        const int rows_in_grp = min(GROUP_M, tiles_m - (int)grp * GROUP_M);
+        const unsigned w_grp = w_in - grp * group_sz;
+        row0 = (grp * GROUP_M + w_grp % rows_in_grp) * BIG;
+        col0 = (w_grp / rows_in_grp) * BIG;
+        ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(A + g * strideA * 4), 0, M * rowb, 0x00020000);
+        brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(B + g * strideB * 4), 0, N * rowb, 0x00020000);
+        // staging: 16-byte piece f -> (row f >> 3, piece f & 7); rows past the edge re-read the last valid row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 512, r = f >> 3, q = f & 7;
+            goff_a[i] = min(row0 + r, M - 1) * rowb + q * 16;
+            goff_b[i] = min(col0 + r, N - 1) * rowb + q * 16;
+        }
+    };
+    u32x4 ra[4], rb[4];
+    auto load_slice = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(ars, goff_a[i], s * 128, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, goff_b[i], s * 128, 0);
+    };
+    auto store_slice = [&](int buf) {
+        unsigned char* base = lds_big + buf * BIG_BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + loff[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(base + BIG * BIG_ROWB + loff[i]) = rb[i];
+    };
+
+    const int a_frag = (wm * 64 + lr) * BIG_ROWB + 16 * lh;                      // + m*32 rows, + part*64, + kg*32
+    const int b_frag = BIG * BIG_ROWB + (wn * 128 + lr) * BIG_ROWB + 16 * lh;
+    const int slices = K / 32;                                                   // even (the host checks K % 64)
+    // transposition slots (half a 32 x 32 block each) behind the two operand buffers: the buffers receive the
+    // next tile's slices while other waves may still be storing
+    float* slot = reinterpret_cast<float*>(lds_big + 2 * BIG_BUF) + wave * 512;
+    const int q = lane >> 3, px4 = (lane & 7) * 4;
+
+    unsigned w = range0 + (blockIdx.x >> 3);
+    if (w >= range1) return;
+    setup(w);
+    load_slice(0);
+    store_slice(0);
+    load_slice(1);
+    __syncthreads();
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+
+    // One body for every slice s (loads and LDS stores outside any branch, so that their waits stay counted):
+    // slice s+1, requested a whole slice earlier, goes from the registers into the buffer that was read
+    // last (everyone has passed the barrier behind those reads), slice s+2 is requested into the same
+    // registers, slice s is multiplied.  Slices past a tile's end are the first two of the workgroup's next
+    // tile (on its last tile: of that tile again -- loaded, stored, never used).
+    auto slice_body = [&](int s) {
+        store_slice((s + 1) & 1);
+        if (s + 2 == slices) setup(w + per_xcd < range1 ? w + per_xcd : w);
+        load_slice(s + 2 < slices ? s + 2 : s + 2 - slices);
+        const unsigned char* base = lds_big + (s & 1) * BIG_BUF;
+        auto read_a = [&](int kg, int part, int m) {
+            return *reinterpret_cast<const bf16x8*>(base + a_frag + m * 32 * BIG_ROWB + part * 64 + kg * 32);
+        };
+        auto read_b = [&](int kg, int part, int n) {
+            return *reinterpret_cast<const bf16x8*>(base + b_frag + n * 32 * BIG_ROWB + part * 64 + kg * 32);
+        };
+        // 8 steps of (k-step, column tile), 6 matrix instructions each; a step issues the reads of the next one
+        bf16x8 fa[2][2][2], fb[2][2];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) fa[0][part][m] = read_a(0, part, m);
+            fb[0][part] = read_b(0, part, 0);
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int kg = st >> 2, n = st & 3, cb = st & 1;
+            if (st + 1 < 8) {
+                fb[cb ^ 1][0] = read_b((st + 1) >> 2, 0, (st + 1) & 3);
+                fb[cb ^ 1][1] = read_b((st + 1) >> 2, 1, (st + 1) & 3);
+            }
+            if (kg == 0) fa[1][n >> 1][n & 1] = read_a(1, n >> 1, n & 1);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                // the small terms first, so that they are not rounded away against the large one
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg][1][m], fb[cb][0], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg][0][m], fb[cb][1], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kg][0][m], fb[cb][0], acc[m][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+
+    // The loop starts with the store of the PREVIOUS tile (of nothing on the first pass: a descriptor of zero
+    // bytes drops every store), so that the multiplication of a tile is always entered from behind the same
+    // 32 branch-free stores: the second slice of the tile, requested before them, is then waited for with a
+    // count that leaves those stores in flight, and they drain under the first slice's matrix instructions.
+    int st_g = 0, st_row0 = 0, st_col0 = 0, st_bytes = 0;
+    for (;;) {
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(C + st_g * strideC, 0, st_bytes, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {               // rows 0..15 of the block, then rows 16..31
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        slot[((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + lr] = acc[m][n][8 * half + e] * inv_divisor;
+                        acc[m][n][8 * half + e] = 0.0f;
+                    }
+                    const int col = st_col0 + wn * 128 + n * 32 + px4;
+                    const int rbase = st_row0 + wm * 64 + m * 32 + 16 * half + q;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(slot + (q + 8 * j) * 32 + px4);
+                        const int row = rbase + 8 * j;
+                        __builtin_amdgcn_raw_buffer_store_b128(t, crs, (row < M && col < N) ? (row * N + col) * 4 : (int)0x80000000, 0, 0);
+                    }
+                }
+        if (w >= range1) break;
+        st_g = g; st_row0 = row0; st_col0 = col0; st_bytes = M * N * 4;
+        slice_body(0);
+        for (int s = 1; s < slices; ++s) slice_body(s);
+        w += per_xcd;
+    }
+}
+
+// Rows of K float32 -> the same 4K bytes per row holding bf16 pieces in blocks of BLK k:
+//   [BLK high parts | BLK low parts] per block, high = bf16(x), low = bf16(x - high).
+// A K-slice of BLK k of one row is then 4*BLK contiguous bytes, laid out as the split kernels keep it in LDS.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, unsigned char* __restrict__ out,
+                                                         int64_t quads, int blk_quads) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // four consecutive k of one row
+    if (i >= quads) return;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
+    const unsigned l0 = pack_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
+    const unsigned l1 = pack_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
+    const int64_t block = i / blk_quads;
+    const int q = (int)(i - block * blk_quads);
+    unsigned char* o = out + block * blk_quads * 16;
+    *reinterpret_cast<uint2*>(o + q * 8) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(o + blk_quads * 8 + q * 8) = make_uint2(l0, l1);
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT, bool PRE = false>
 int launch_corr(const float* A, const float* B, float* C, int groups, int M, int N, int K, int64_t sA,
                 int64_t sB, int64_t sC, float divisor, hipStream_t stream, const char* name) {
     const int tiles_m = (int)vo_ceil_div(M, BM), tiles_n = (int)vo_ceil_div(N, BN);
     const int64_t nwg = (int64_t)tiles_m * tiles_n * groups;
     if (nwg > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: %lld workgroups", name, (long long)nwg);
     constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + PAD) * sizeof(float);
-    auto kern = corr_abt_kernel<BM, BN, BK, WAVES_M, WAVES_N, SPLIT>;
+    static_assert(lds >= (size_t)WAVES_M * WAVES_N * 4096, "the store path's transposition slots do not fit");
+    auto kern = corr_abt_kernel<BM, BN, BK, WAVES_M, WAVES_N, SPLIT, PRE>;
     if (lds > 48 * 1024) {
         // the attribute is kept per device and setting it is a cheap host call: set it on every
         // launch rather than remember it in a flag that another device or thread would not share
@@ -263,8 +490,10 @@ int launch_corr(const float* A, const float* B, float* C, int groups, int M, int
     return VO_OK;
 }
 
+// mode 0: float32 products; 1: float32 rows split into bf16 pieces inside the kernel; 2: rows already split
+// (split_rows_kernel's format, blocks of 32 k for the large tile and of 16 k for the small one)
 int corr_abt(const float* A, const float* B, float* C, int groups, int M, int N, int K, int64_t sA, int64_t sB,
-             int64_t sC, hipStream_t stream, const char* name, bool split = false) {
+             int64_t sC, hipStream_t stream, const char* name, int mode = 0, int force_small = -1) {
     if (!A || !B || !C) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
     if (groups <= 0 || M <= 0 || N <= 0 || K <= 0)
         return vo_fail(VO_ERR_INVALID_ARG, "%s: non-positive size (groups=%d M=%d N=%d K=%d)", name, groups, M, N, K);
@@ -275,8 +504,39 @@ int corr_abt(const float* A, const float* B, float* C, int groups, int M, int N,
     // Small matrices (one image row of RAFT-Stereo) get one 160-wide tile per
     // workgroup; the big flow volume gets 128x128 tiles.
     // the kernels take K in pairs of slices: 2 x 16 for the small tile, 2 x 32 for the large one
-    const bool small = (M <= 512 && N <= 512) || K % 64 != 0;
-    if (split) {
+    bool small = (M <= 512 && N <= 512) || K % 64 != 0;
+    if (force_small >= 0) {
+        if (!force_small && K % 64 != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: feature dim %d is not a multiple of 64", name, K);
+        small = force_small != 0;
+    }
+    if (mode == 2 && !small && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && (sC & 3) == 0 &&
+        (int64_t)std::max(M, N) * K * 4 < 0x7fffffffLL && (int64_t)M * N * 4 < 0x7fffffffLL) {
+        const int tiles_m = (int)vo_ceil_div(M, BIG), tiles_n = (int)vo_ceil_div(N, BIG);
+        const int64_t nwork = (int64_t)tiles_m * tiles_n * groups;
+        if (nwork > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: %lld tiles", name, (long long)nwork);
+        constexpr int lds = 2 * BIG_BUF + 8 * 2048;
+        static_assert(lds <= 160 * 1024, "the operand buffers and the slots exceed the LDS of a CU");
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_presplit_big_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: LDS attribute: %s", name, hipGetErrorString(e));
+        // one workgroup per CU (a multiple of 8, one share per XCD); a workgroup with no item returns at once
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        const unsigned grid = (unsigned)std::min<int64_t>((cus + 7) / 8 * 8, (nwork + 7) / 8 * 8);
+        corr_presplit_big_kernel<<<dim3(grid), dim3(512), lds, stream>>>(
+            reinterpret_cast<const unsigned char*>(A), reinterpret_cast<const unsigned char*>(B), C, M, N, K, sA, sB, sC, tiles_m,
+            tiles_n, (unsigned)nwork, 1.0f / divisor);
+        e = hipGetLastError();
+        if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
+        return VO_OK;
+    }
+    if (mode == 2) {
+        if (small)
+            return launch_corr<160, 160, 16, 1, 5, true, true>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+        return launch_corr<128, 128, 32, 2, 2, true, true>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
+    }
+    if (mode == 1) {
         if (small)
             return launch_corr<160, 160, 16, 1, 5, true>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
         return launch_corr<128, 128, 32, 2, 2, true>(A, B, C, groups, M, N, K, sA, sB, sC, divisor, stream, name);
@@ -311,7 +571,7 @@ extern "C" int vo_corr_volume_2d_bf16x3(const float* fmap1, const float* fmap2, 
     const int64_t n = (int64_t)H * W;
     VO_REQUIRE(n <= (1 << 20), "vo_corr_volume_2d_bf16x3: %lld pixels per feature map is beyond the supported 2^20", (long long)n);
     return corr_abt(fmap1, fmap2, corr, batch, (int)n, (int)n, D, n * D, n * D, n * n, vo_stream(stream),
-                    "vo_corr_volume_2d_bf16x3", true);
+                    "vo_corr_volume_2d_bf16x3", 1);
 }
 
 extern "C" int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, float* corr, int batch, int H, int W1,
@@ -319,7 +579,7 @@ extern "C" int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, 
     VO_REQUIRE(batch > 0 && H > 0, "vo_corr_volume_1d_bf16x3: bad size batch=%d H=%d", batch, H);
     VO_REQUIRE((int64_t)batch * H <= 0x7fffffffLL, "vo_corr_volume_1d_bf16x3: batch*H too large");
     return corr_abt(fmap1, fmap2, corr, batch * H, W1, W2, D, (int64_t)W1 * D, (int64_t)W2 * D, (int64_t)W1 * W2,
-                    vo_stream(stream), "vo_corr_volume_1d_bf16x3", true);
+                    vo_stream(stream), "vo_corr_volume_1d_bf16x3", 1);
 }
 
 extern "C" int vo_corr_volume_mn(const float* fmap1, const float* fmap2, float* corr, int batch, int M, int N, int D, int split,
@@ -327,5 +587,36 @@ extern "C" int vo_corr_volume_mn(const float* fmap1, const float* fmap2, float* 
     VO_REQUIRE(M > 0 && N > 0, "vo_corr_volume_mn: bad size M=%d N=%d", M, N);
     VO_REQUIRE(M <= (1 << 20) && N <= (1 << 21), "vo_corr_volume_mn: matrix sides beyond the supported 2^20 x 2^21");
     return corr_abt(fmap1, fmap2, corr, batch, M, N, D, (int64_t)M * D, (int64_t)N * D, (int64_t)M * N, vo_stream(stream),
-                    "vo_corr_volume_mn", split != 0);
+                    "vo_corr_volume_mn", split != 0 ? 1 : 0);
+}
+
+extern "C" int vo_split_feature_rows(const float* x, void* out, int64_t rows, int D, int block, void* stream) {
+    VO_REQUIRE(x && out, "vo_split_feature_rows: null pointer");
+    VO_REQUIRE(rows > 0 && D > 0, "vo_split_feature_rows: bad sizes rows=%lld D=%d", (long long)rows, D);
+    VO_REQUIRE(block == 16 || block == 32, "vo_split_feature_rows: block must be 16 or 32, got %d", block);
+    VO_REQUIRE(D % block == 0, "vo_split_feature_rows: D=%d is not a multiple of the block %d", D, block);
+    VO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "vo_split_feature_rows: tensors must be 16-byte aligned");
+    VO_REQUIRE(static_cast<const void*>(x) != out, "vo_split_feature_rows: not in place");
+    const int64_t quads = rows * D / 4;
+    split_rows_kernel<<<dim3((unsigned)vo_ceil_div(quads, 256)), dim3(256), 0, vo_stream(stream)>>>(x, static_cast<unsigned char*>(out), quads, block / 4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "vo_split_feature_rows: %s", hipGetErrorString(e));
+    return VO_OK;
+}
+
+extern "C" int vo_corr_volume_2d_presplit(const void* fmap1, const void* fmap2, float* corr, int batch, int H, int W,
+                                          int D, void* stream) {
+    VO_REQUIRE(H > 0 && W > 0, "vo_corr_volume_2d_presplit: bad size H=%d W=%d", H, W);
+    const int64_t n = (int64_t)H * W;
+    VO_REQUIRE(n <= (1 << 20), "vo_corr_volume_2d_presplit: %lld pixels per feature map is beyond the supported 2^20", (long long)n);
+    return corr_abt(static_cast<const float*>(fmap1), static_cast<const float*>(fmap2), corr, batch, (int)n, (int)n, D, n * D,
+                    n * D, n * n, vo_stream(stream), "vo_corr_volume_2d_presplit", 2, 0);
+}
+
+extern "C" int vo_corr_volume_1d_presplit(const void* fmap1, const void* fmap2, float* corr, int batch, int H, int W1,
+                                          int W2, int D, void* stream) {
+    VO_REQUIRE(batch > 0 && H > 0, "vo_corr_volume_1d_presplit: bad size batch=%d H=%d", batch, H);
+    VO_REQUIRE((int64_t)batch * H <= 0x7fffffffLL, "vo_corr_volume_1d_presplit: batch*H too large");
+    return corr_abt(static_cast<const float*>(fmap1), static_cast<const float*>(fmap2), corr, batch * H, W1, W2, D,
+                    (int64_t)W1 * D, (int64_t)W2 * D, (int64_t)W1 * W2, vo_stream(stream), "vo_corr_volume_1d_presplit", 2, 1);
 }

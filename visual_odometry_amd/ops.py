@@ -427,18 +427,21 @@ def conv1x1_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.
 
 
 def conv1x1_pixel_major_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
-                              shift: torch.Tensor | None = None, relu: bool = False) -> torch.Tensor:
-    """conv1x1_split with the output in pixel-major order: x (N,C,H,W) float32 -> (N,H,W,K), K a multiple of 4."""
+                              shift: torch.Tensor | None = None, relu: bool = False, split_rows: bool = False) -> torch.Tensor:
+    """conv1x1_split with the output in pixel-major order: x (N,C,H,W) float32 -> (N,H,W,K), K a multiple of 4.
+    ``split_rows``: the rows leave as bf16 pieces in blocks of 32 channels (the form of split_feature_rows(., 32),
+    K a multiple of 32): bytes for corr_volume_2d_presplit, not float32 numbers."""
     N, C, H, W = x.shape
-    if arranged.numel() != (K + 63) // 64 * 64 * C or K % 4:
-        raise ValueError("arranged weights do not match (K, C), K a multiple of 4")
+    if arranged.numel() != (K + 63) // 64 * 64 * C or K % (32 if split_rows else 4):
+        raise ValueError("arranged weights do not match (K, C), K a multiple of 4 (of 32 for split rows)")
     if W % 2:
         raise ValueError("the split-bf16 kernel needs an even width")
     for t, name in ((scale, "scale"), (shift, "shift")):
         if t is not None and t.numel() != K:
             raise ValueError(f"{name} must have one entry per output channel")
     out = torch.empty((N, H, W, K), device=x.device, dtype=torch.float32)
-    _call("vo_conv1x1_pixel_major_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
+    _call("vo_conv1x1_split_rows_bf16x3" if split_rows else "vo_conv1x1_pixel_major_bf16x3", _dev(x, "x", torch.float32),
+          _dev(arranged, "weights", torch.float32), out.data_ptr(),
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
           nbytes=4 * (x.numel() + out.numel()), flops=2 * 3 * N * K * C * H * W)
     return out
@@ -802,6 +805,40 @@ def corr_volume_1d(fmap1: torch.Tensor, fmap2: torch.Tensor, split: bool = False
     corr = torch.empty((B, H, W1, W2), device=fmap1.device, dtype=torch.float32)
     _call("vo_corr_volume_1d_bf16x3" if split else "vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32),
           _dev(fmap2, "fmap2", torch.float32), corr.data_ptr(), B, H, W1, W2, D, _stream())
+    return corr
+
+
+def split_feature_rows(fmap: torch.Tensor, block: int) -> torch.Tensor:
+    """Pixel-major feature maps (..., D) float32 -> a tensor of the same shape and dtype whose BYTES are the
+    maps' bf16 pieces: per row and block of ``block`` features, ``block`` high parts then ``block`` low
+    parts (high = bf16(x), low = bf16(x - high)).  What the ``presplit`` correlation kernels read: 32 for
+    corr_volume_2d_presplit, 16 for corr_volume_1d_presplit.  The values are not float32 numbers any more."""
+    D = fmap.shape[-1]
+    out = torch.empty_like(fmap)
+    _call("vo_split_feature_rows", _dev(fmap, "fmap", torch.float32), out.data_ptr(), fmap.numel() // D, D, block, _stream())
+    return out
+
+
+def corr_volume_2d_presplit(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+    """corr_volume_2d(split=True) on feature maps already in split_feature_rows(., 32) form."""
+    B, H, W, D = fmap1.shape
+    if fmap2.shape != fmap1.shape:
+        raise ValueError("fmap1 and fmap2 must have the same shape")
+    corr = torch.empty((B, H * W, H, W), device=fmap1.device, dtype=torch.float32)
+    _call("vo_corr_volume_2d_presplit", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+          corr.data_ptr(), B, H, W, D, _stream())
+    return corr
+
+
+def corr_volume_1d_presplit(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+    """corr_volume_1d(split=True) on feature maps already in split_feature_rows(., 16) form."""
+    B, H, W1, D = fmap1.shape
+    if fmap2.shape[0] != B or fmap2.shape[1] != H or fmap2.shape[3] != D:
+        raise ValueError("fmap2 must be (B,H,W2,D) matching fmap1")
+    W2 = fmap2.shape[2]
+    corr = torch.empty((B, H, W1, W2), device=fmap1.device, dtype=torch.float32)
+    _call("vo_corr_volume_1d_presplit", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+          corr.data_ptr(), B, H, W1, W2, D, _stream())
     return corr
 
 

@@ -99,19 +99,23 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     return F.conv2d(x, w, conv._vo_weight_cast[2], conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
-def conv_pixel_major(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+def conv_pixel_major(x: torch.Tensor, conv: nn.Conv2d, split_rows: bool = False) -> torch.Tensor:
     """conv(x) with bias as float32 (N,H,W,K): each pixel's feature vector contiguous, the layout
     the correlation kernels read.  A float32 1x1 convolution writes it directly; anything else is
-    the convolution followed by the permuting copy."""
+    the convolution followed by the permuting copy.  ``split_rows``: the rows as bf16 pieces in blocks
+    of 32 channels (ops.split_feature_rows(., 32)), written by the convolution's store where that
+    kernel applies, by a pass over the float32 rows otherwise."""
     if (x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and fused_on() and conv.bias is not None and x.is_cuda):
-        if conv.out_channels % 4 == 0 and x.is_contiguous():
+        if conv.out_channels % (32 if split_rows else 4) == 0 and x.is_contiguous():
             Ws = _conv1x1_split_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Ws is not None:
-                return ops.conv1x1_pixel_major_split(x, Ws, conv.out_channels, None, conv.bias, False)
+                return ops.conv1x1_pixel_major_split(x, Ws, conv.out_channels, None, conv.bias, False, split_rows)
         Wg = _conv1x1_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
         if Wg is not None:
-            return ops.conv1x1_pixel_major(x, Wg, conv.out_channels, None, conv.bias, False)
-    return conv_plain(x, conv).float().permute(0, 2, 3, 1).contiguous()
+            y = ops.conv1x1_pixel_major(x, Wg, conv.out_channels, None, conv.bias, False)
+            return ops.split_feature_rows(y, 32) if split_rows else y
+    y = conv_plain(x, conv).float().permute(0, 2, 3, 1).contiguous()
+    return ops.split_feature_rows(y, 32) if split_rows else y
 
 
 _WINOGRAD = True            # float32 3x3 stride-1 convolutions on the hand-written Winograd/MFMA kernels
@@ -701,12 +705,13 @@ class BasicEncoder(nn.Module):
         self.in_planes = dim
         return blocks
 
-    def forward(self, x: torch.Tensor, pixel_major: bool = False) -> torch.Tensor:
-        """``pixel_major``: return float32 (B,H,W,D) instead of (B,D,H,W).  x: three channels, or the
-        one plane of a gray frame."""
+    def forward(self, x: torch.Tensor, pixel_major: bool = False, split_rows: bool = False) -> torch.Tensor:
+        """``pixel_major``: return float32 (B,H,W,D) instead of (B,D,H,W); with ``split_rows`` the
+        (B,H,W,D) rows as bf16 pieces (see conv_pixel_major).  x: three channels, or the one plane of a
+        gray frame."""
         x = conv_norm_act(x, gray_stem(self.conv1, x), self.norm1, True, lazy=True)     # a RawNorm when the stem leaves its sums
         x = self.layer3(self.layer2(self.layer1(x)))
-        return conv_pixel_major(x, self.conv2) if pixel_major else conv_plain(x, self.conv2)
+        return conv_pixel_major(x, self.conv2, split_rows) if pixel_major else conv_plain(x, self.conv2)
 
 
 class MultiBasicEncoder(nn.Module):

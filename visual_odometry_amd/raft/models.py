@@ -79,19 +79,25 @@ class RAFTFlow(nn.Module):
     def _act_dtype(self):
         return torch.float16 if self.mixed_precision else torch.float32
 
+    def presplit_features(self) -> bool:
+        """True when features() hands the correlation kernel rows that are already split into bf16
+        pieces (ops.split_feature_rows(., 32)): under the split-bf16 arithmetic, outside mixed precision.
+        Such maps are bytes for that kernel, not float32 numbers."""
+        return split_bf16_on() and not self.mixed_precision
+
     @torch.no_grad()
     def features(self, images: torch.Tensor) -> torch.Tensor:
-        """Normalised images (B,3,H,W) -> pixel-major feature maps (B,H/8,W/8,256)."""
+        """Normalised images (B,3,H,W) -> pixel-major feature maps (B,H/8,W/8,256); see presplit_features."""
         with fused_passes():
-            return self.fnet(images.to(self._act_dtype()), pixel_major=True)
+            return self.fnet(images.to(self._act_dtype()), pixel_major=True, split_rows=self.presplit_features())
 
     @torch.no_grad()
     def forward(self, image1, image2, iters: int = 12, flow_init=None, fmap1=None, fmap2=None,
                 normalized: bool = False):
         """image1/2: (B,3,H,W) float 0..255 (or already in [-1,1] with
-        ``normalized=True``), H and W multiples of 8.  Precomputed pixel-major
-        feature maps may be passed so that consecutive pairs of a sequence share
-        the encoder pass of their common frame."""
+        ``normalized=True``), H and W multiples of 8.  Precomputed feature maps
+        (what features() returns under the current arithmetic) may be passed so that
+        consecutive pairs of a sequence share the encoder pass of their common frame."""
         c = self.cfg
         if not normalized:
             image1 = normalize_image(image1)
@@ -104,7 +110,10 @@ class RAFTFlow(nn.Module):
 
         # row-major target order: the tiled order (ops.corr_*_tiled) gives identical values but was measured
         # slower and heavier on the memory counters for the lookup's gathers
-        corr = ops.corr_volume_2d(fmap1, fmap2, split=split_bf16_on())
+        if self.presplit_features():
+            corr = ops.corr_volume_2d_presplit(fmap1.contiguous(), fmap2.contiguous())
+        else:
+            corr = ops.corr_volume_2d(fmap1, fmap2, split=split_bf16_on())
         pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
 
         act = self._act_dtype()
