@@ -1,0 +1,282 @@
+// What the staging work of the split-bf16 convolution costs the matrix instructions of the wave it shares a
+// SIMD with.  One workgroup of 8 waves per CU: waves 0-3 run the multiply phase of the 3x3 kernel out of LDS
+// (tools/mfma_shape_probe.hip, 32x32x16 form), waves 4-7 (the SIMD partners of waves 0-3) run, chunk for chunk
+// and with no barrier between the two roles, one component of the staging work of a chunk:
+//   0 nothing   1 the conversions (float32 -> high and low bf16 parts, 16 values x 3 rounds per lane)
+//   2 the LDS stores (21 x 16 bytes per lane)   3 the global loads (24 x 8 bytes + 9 x 16 bytes per lane, L2-resident)
+//   4 all three   5 all three, half the multiply chunks (staging-bound reference)
+//   6 all three with one workgroup barrier per chunk between the roles (a double-buffered hand-over)
+// Prints the time of the launch and the multiply role's rate.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/staging_interference.hip -o tools/bin/staging_interference
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PL = 18 * 36 * 16;
+constexpr int PATCH = 4 * PL;                // [part][k-half][row][column][8 channels]
+constexpr int WEIGHTS = 9 * 4 * 1024;        // [tap][part][m-tile][lane][16 bytes]
+constexpr int LDS = PATCH + WEIGHTS;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void roles(const unsigned* src, const float* gx, float* out, int chunks) {
+    extern __shared__ __align__(16) unsigned char lds[];      // multiply operands | the stagers' target
+    for (int i = threadIdx.x; i < LDS / 4; i += 512) reinterpret_cast<unsigned*>(lds)[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < 4) {
+        const unsigned char* a_lds = lds + PATCH + lane * 16;
+        const unsigned char* b_lds = lds + (lane >> 5) * PL + ((4 * wave) * 36 + (lane & 31)) * 16;
+        f32x16 acc[2][4];
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+        const int mine = MODE == 5 ? chunks / 2 : chunks;
+        for (int c = 0; c < mine; ++c) {
+            bf16x8 fa[2][2][2], fb[2][2];
+            for (int part = 0; part < 2; ++part) {
+                for (int mt = 0; mt < 2; ++mt) fa[0][part][mt] = *reinterpret_cast<const bf16x8*>(a_lds + (part * 2 + mt) * 1024);
+                fb[0][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL);
+            }
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+                const int tap = st / 4, nt = st % 4, ca = tap & 1, cb = st & 1;
+                if (st + 1 < 36) {
+                    const int t2 = (st + 1) / 4, n2 = (st + 1) % 4;
+                    for (int part = 0; part < 2; ++part)
+                        fb[cb ^ 1][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL + ((n2 + t2 / 3) * 36 + t2 % 3) * 16);
+                }
+                if (tap + 1 < 9) { const int f = nt; fa[ca ^ 1][f / 2][f % 2] = *reinterpret_cast<const bf16x8*>(a_lds + (((tap + 1) * 2 + f / 2) * 2 + f % 2) * 1024); }
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][1][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 6) __syncthreads();
+        }
+        float s = 0;
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) s += acc[m][n][e];
+        if (s == 123.456f) out[threadIdx.x] = s;
+        return;
+    }
+    if (MODE == 0) return;
+    // the staging role: per chunk and lane 3 rounds of (8 channels x 2 pixels) -> 2 x (high, low) 16-byte LDS entries,
+    // and 9 x 16 bytes of weights copied
+    const int t = threadIdx.x - 256;
+    unsigned char* target = lds + LDS;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx) + (size_t)blockIdx.x * 131072, 0, 131072 * 4, 0x00020000);
+    u32x2 rv[3][8];
+    u32x4 aw[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j) rv[i][j] = u32x2{(unsigned)(0x3f800000 + t * 977 + i * 131 + j), (unsigned)(0x3f000000 + t * 31 + j * 7)};
+    for (int i = 0; i < 9; ++i) aw[i] = u32x4{(unsigned)t, (unsigned)i, 3u, 4u};
+    unsigned sink = 0;
+    for (int c = 0; c < chunks; ++c) {
+        if (MODE == 3 || MODE >= 4) {
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j)
+                rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (t + i * 256) * 8, ((c & 3) * 8 + j) * 6144, 0);
+            for (int i = 0; i < 9; ++i) aw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (t + i * 256) * 16, 196608 + (c & 1) * 36864, 0);
+        }
+        for (int i = 0; i < 3; ++i) {
+            u32x4 hi[2], lo[2];
+            for (int px = 0; px < 2; ++px) {
+                if (MODE == 1 || MODE >= 4) {
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float a = __uint_as_float(rv[i][2 * jj][px]), b = __uint_as_float(rv[i][2 * jj + 1][px]);
+                        const unsigned h = pack_bf16(a, b);
+                        hi[px][jj] = h;
+                        lo[px][jj] = pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+                    }
+                } else {
+                    for (int jj = 0; jj < 4; ++jj) { hi[px][jj] = rv[i][2 * jj][px]; lo[px][jj] = rv[i][2 * jj + 1][px]; }
+                }
+            }
+            if (MODE == 2 || MODE >= 4) {
+                for (int px = 0; px < 2; ++px) {
+                    *reinterpret_cast<u32x4*>(target + ((i * 256 + t) * 2 + px) * 16) = hi[px];
+                    *reinterpret_cast<u32x4*>(target + 2 * PL + ((i * 256 + t) * 2 + px) * 16) = lo[px];
+                }
+            } else {
+                for (int px = 0; px < 2; ++px) sink ^= hi[px][0] ^ hi[px][3] ^ lo[px][1] ^ lo[px][2] ^ hi[px][1] ^ hi[px][2] ^ lo[px][0] ^ lo[px][3];
+                // keep the next chunk's conversions from folding into this one
+                for (int j = 0; j < 8; ++j) rv[i][j][0] += sink & 1;
+            }
+        }
+        if (MODE == 2 || MODE >= 4)
+            for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(target + PATCH + (t + i * 256) * 16) = aw[i];
+        else
+            for (int i = 0; i < 9; ++i) sink ^= aw[i][0];
+        if (MODE == 6) __syncthreads();
+    }
+    if (sink == 0x12345678u) out[threadIdx.x] = 1.0f;
+}
+
+
+// The production structure: 4 waves that alternate between staging a chunk (conversions + LDS stores of the patch
+// and the weights, then a barrier) and multiplying it (the next chunk's global loads requested first; a barrier
+// behind), two such workgroups per CU.  PARTS: bit 0 = the staging work, bit 1 = the multiply phase; staging minus
+// a component: bit 2 = no conversions, bit 3 = no copy of the weights, bit 4 = no LDS stores of the patch, bit 5 = no global loads;
+// bit 6 = the global loads issued one per (tap, pixel tile) step of the multiply phase instead of in two bursts.
+template <int PARTS>
+__global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const float* gx, float* out, int chunks) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    for (int i = threadIdx.x; i < LDS / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = threadIdx.x;
+    const unsigned char* a_lds = lds + PATCH + lane * 16;
+    const unsigned char* b_lds = lds + (lane >> 5) * PL + ((4 * wave) * 36 + (lane & 31)) * 16;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx) + (size_t)(blockIdx.x & 255) * 131072, 0, 131072 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(src), 0, LDS, 0x00020000);
+    f32x16 acc[2][4];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+    u32x2 rv[3][8];
+    u32x4 aw[9];
+    auto load_raw = [&](int c) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j)
+            rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (t + i * 256) * 8, ((c & 3) * 8 + j) * 6144, 0);
+    };
+    auto load_aw = [&](int c) {
+        for (int i = 0; i < 9; ++i) aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ws, (t + i * 256) * 16, PATCH, 0);
+    };
+    load_raw(0); load_aw(0);
+    for (int c = 0; c < chunks; ++c) {
+        if (PARTS & 1) {
+            for (int i = 0; i < 3; ++i) {
+                if (i == 2 && t >= 136) continue;                    // 648 units over 256 lanes
+                for (int px = 0; px < 2; ++px) {
+                    u32x4 hi, lo;
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float a = __uint_as_float(rv[i][2 * jj][px]), b = __uint_as_float(rv[i][2 * jj + 1][px]);
+                        if (PARTS & 4) { hi[jj] = rv[i][2 * jj][px]; lo[jj] = rv[i][2 * jj + 1][px]; continue; }
+                        const unsigned h = pack_bf16(a, b);
+                        hi[jj] = h;
+                        lo[jj] = pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+                    }
+                    const int u = i * 256 + t, kg = u / 324, rem = u - kg * 324;
+                    if (PARTS & 16) { if ((hi[0] ^ lo[3] ^ hi[1] ^ hi[2] ^ hi[3] ^ lo[0] ^ lo[1] ^ lo[2]) == 0x12345u) out[t] = 2.0f; continue; }
+                    *reinterpret_cast<u32x4*>(lds + kg * PL + (rem * 2 + px) * 16) = hi;
+                    *reinterpret_cast<u32x4*>(lds + 2 * PL + kg * PL + (rem * 2 + px) * 16) = lo;
+                }
+            }
+            if (!(PARTS & 8)) for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(lds + PATCH + (t + i * 256) * 16) = aw[i];
+        }
+        __syncthreads();
+        if ((PARTS & 1) && !(PARTS & (32 | 64))) load_raw(c + 1);
+        if (PARTS & 2) {
+            bf16x8 fa[2][2][2], fb[2][2];
+            for (int part = 0; part < 2; ++part) {
+                for (int mt = 0; mt < 2; ++mt) fa[0][part][mt] = *reinterpret_cast<const bf16x8*>(a_lds + (part * 2 + mt) * 1024);
+                fb[0][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL);
+            }
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+                const int tap = st / 4, nt = st % 4, ca = tap & 1, cb = st & 1;
+                if (st + 1 < 36) {
+                    const int t2 = (st + 1) / 4, n2 = (st + 1) % 4;
+                    for (int part = 0; part < 2; ++part)
+                        fb[cb ^ 1][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL + ((n2 + t2 / 3) * 36 + t2 % 3) * 16);
+                }
+                if (tap + 1 < 9) { const int f = nt; fa[ca ^ 1][f / 2][f % 2] = *reinterpret_cast<const bf16x8*>(a_lds + (((tap + 1) * 2 + f / 2) * 2 + f % 2) * 1024); }
+                if ((PARTS & 64) && (PARTS & 1)) {
+                    if (st < 24) rv[st / 8][st % 8] = __builtin_amdgcn_raw_buffer_load_b64(rs, (t + (st / 8) * 256) * 8, (((c + 1) & 3) * 8 + st % 8) * 6144, 0);
+                    else if (st >= 27) aw[st - 27] = __builtin_amdgcn_raw_buffer_load_b128(ws, (t + (st - 27) * 256) * 16, PATCH, 0);
+                }
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][1][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                }
+                if (PARTS & 64) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if ((PARTS & 1) && !(PARTS & (40 | 64))) load_aw(c + 1);
+        __syncthreads();
+    }
+    float s = 0;
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) s += acc[m][n][e];
+    for (int i = 0; i < 3; ++i) s += __uint_as_float(rv[i][0][0]);
+    s += __uint_as_float(aw[0][0]);
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+template <int PARTS>
+int run_alt(const unsigned* src, const float* gx, float* out, int chunks, int blocks) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(alternating<PARTS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return 1;
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        alternating<PARTS><<<blocks, 256, LDS>>>(src, gx, out, chunks);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    const double flops = 2.0 * 216 * 32 * 32 * 16 * 4.0 * blocks * chunks;
+    printf("alternating phases, %d workgroups, parts %d (1 staging, 2 multiply): %.3f ms", blocks, PARTS, best);
+    if (PARTS & 2) printf(", %.0f TFLOP/s", flops / best / 1e9);
+    printf("\n");
+    return 0;
+}
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int MODE>
+int run(const unsigned* src, const float* gx, float* out, int chunks) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int lds = 2 * LDS;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(roles<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0));
+        roles<MODE><<<256, 512, lds>>>(src, gx, out, chunks);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    const int mine = MODE == 5 ? chunks / 2 : chunks;
+    const double flops = 2.0 * 216 * 32 * 32 * 16 * 4.0 * 256 * mine;
+    printf("staging component %d: %.3f ms, multiply role %.0f TFLOP/s\n", MODE, best, flops / best / 1e9);
+    return 0;
+}
+
+int main() {
+    std::vector<unsigned> h(LDS / 4);
+    srand(1);
+    for (auto& v : h) {
+        auto r = []() { union { float f; unsigned u; } c; c.f = (rand() / (float)RAND_MAX) * 2.0f - 1.0f; return c.u >> 16; };
+        v = r() | (r() << 16);
+    }
+    std::vector<float> g(256 * 131072);
+    for (auto& v : g) v = (rand() / (float)RAND_MAX) * 2.0f - 1.0f;
+    unsigned* src; float* out; float* gx;
+    CHECK(hipMalloc(&src, LDS)); CHECK(hipMalloc(&out, 4096)); CHECK(hipMalloc(&gx, g.size() * 4));
+    CHECK(hipMemcpy(src, h.data(), LDS, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(gx, g.data(), g.size() * 4, hipMemcpyHostToDevice));
+    const int chunks = 400;
+    for (int blocks = 256; blocks <= 512; blocks += 256)
+        for (int round = 0; round < 1; ++round)
+            if (run_alt<2>(src, gx, out, chunks, blocks) || run_alt<1>(src, gx, out, chunks, blocks) || run_alt<3>(src, gx, out, chunks, blocks) ||
+                run_alt<1 + 4>(src, gx, out, chunks, blocks) || run_alt<1 + 8>(src, gx, out, chunks, blocks) || run_alt<1 + 16>(src, gx, out, chunks, blocks) ||
+                run_alt<1 + 32>(src, gx, out, chunks, blocks) || run_alt<3 + 4>(src, gx, out, chunks, blocks) || run_alt<3 + 8>(src, gx, out, chunks, blocks) ||
+                run_alt<3 + 16>(src, gx, out, chunks, blocks) || run_alt<3 + 32>(src, gx, out, chunks, blocks) || run_alt<3 + 64>(src, gx, out, chunks, blocks) ||
+                run_alt<3>(src, gx, out, chunks, blocks) || run_alt<3 + 64>(src, gx, out, chunks, blocks)) return 1;
+    for (int round = 0; round < 1; ++round) {
+        if (run<0>(src, gx, out, chunks) || run<1>(src, gx, out, chunks) || run<2>(src, gx, out, chunks) || run<3>(src, gx, out, chunks) ||
+            run<4>(src, gx, out, chunks) || run<5>(src, gx, out, chunks) || run<6>(src, gx, out, chunks)) return 1;
+    }
+    return 0;
+}
