@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void corr_presplit_big_kernel(
                     for (int j = 0; j < 2; ++j) {
                         const u32x4 t = *reinterpret_cast<const u32x4*>(slot + (q + 8 * j) * 32 + px4);
                         const int row = rbase + 8 * j;
-                        __builtin_amdgcn_raw_buffer_store_b128(t, crs, (row < M && col < N) ? (row * N + col) * 4 : (int)0x80000000, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(t, crs, (row < M && col < N) ? (row * N + col) * 4 : (int)0x80000000, 0, 2);   // nontemporal: the volume streams out, the feature tiles stay in L2
                     }
                 }
         if (w >= range1) break;
