@@ -197,8 +197,10 @@ def _coords(B, H, W, seed, spread):
     return c
 
 
-@pytest.mark.parametrize("B,H,W,radius,levels", [(1, 16, 24, 4, 4), (2, 8, 16, 3, 3), (1, 60, 80, 4, 4)])
+@pytest.mark.parametrize("B,H,W,radius,levels", [(1, 16, 24, 4, 4), (2, 8, 16, 3, 3), (1, 60, 80, 4, 4), (2, 9, 13, 4, 3), (1, 7, 11, 3, 2)])
 def test_lookup_2d(vo, B, H, W, radius, levels):
+    """Sizes with and without a multiple of four pixels, and the output written as the leading channels of a
+    wider tensor (a batch stride)."""
     from visual_odometry_amd import ops
     N = H * W
     if N > 1000:                      # full 640x480 geometry: build the volume on the GPU
@@ -221,9 +223,14 @@ def test_lookup_2d(vo, B, H, W, radius, levels):
     centre = radius * (2 * radius + 1) + radius
     diag = pyr[0].cpu().view(B, N, N).diagonal(dim1=1, dim2=2).reshape(B, H, W)
     assert torch.equal(exact[:, centre], diag)
+    # written into the leading channels of a wider tensor: same values, the other channels untouched
+    ch = got.shape[1]
+    wide = torch.full((B, ch + 5, H, W), 7.5, device=DEV)
+    ops.corr_lookup_2d(pyr, coords.to(DEV), radius, out=wide[:, :ch])
+    assert torch.equal(wide[:, :ch], got) and torch.all(wide[:, ch:] == 7.5)
 
 
-@pytest.mark.parametrize("B,H,W,radius", [(1, 6, 40, 4), (2, 4, 37, 3), (1, 120, 160, 4)])
+@pytest.mark.parametrize("B,H,W,radius", [(1, 6, 40, 4), (2, 4, 37, 3), (1, 120, 160, 4), (1, 5, 37, 4)])
 def test_lookup_1d(vo, B, H, W, radius):
     from visual_odometry_amd import ops
     pyr = ops.corr_pyramid_1d(_rand(B, H, W, W, seed=12).to(DEV), 4)
