@@ -281,11 +281,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # One rank per GPU over RCCL.  With fewer GPUs than local ranks (a rehearsal of the multi-rank path on a one-GPU
+    # box: ranks share the card, use a small --batch) the ranks rendezvous over gloo instead: RCCL refuses two ranks on
+    # one device; the hot path has no collective either way.
+    n_dev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    shared_card = n_dev < local_world
+    torch.cuda.set_device(local_rank % n_dev)
     dist = None
     if world > 1 or os.environ.get("TORCHELASTIC_RUN_ID"):       # launched by torch.distributed.run (any world size)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_card:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from visual_odometry_amd import ops, synthetic as syn
     from visual_odometry_amd.pipeline import VisualOdometry, VOConfig
@@ -335,7 +344,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if shared_card else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
