@@ -41,7 +41,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak
 # kernels whose float32 products are three bf16 matrix-core terms: their recorded FLOPs are the bf16
 # multiply-adds they issue (three per product), priced against the bf16 peak
-SPLIT_BF16_KERNELS = ("vo_conv3x3_bf16x3", "vo_conv5_bf16x3", "vo_conv3x3s2_bf16x3", "vo_conv1x1s2_bf16x3", "vo_conv7x7_bf16x3",
+SPLIT_BF16_KERNELS = ("vo_conv3x3_bf16x3", "vo_conv5_bf16x3", "vo_conv3x3s2_bf16x3", "vo_conv3x3s2_shortcut_bf16x3", "vo_conv1x1s2_bf16x3",
+                      "vo_conv7x7_bf16x3",
                       "vo_corr_volume_2d_bf16x3", "vo_corr_volume_1d_bf16x3", "vo_corr_volume_2d_presplit")
 
 
@@ -79,7 +80,7 @@ def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256
 PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_corr_pyramid_2d": "pyr2d",
             "vo_corr_pyramid_1d": "pyr1d", "vo_corr_lookup_2d": "lookup2d", "vo_corr_lookup_1d": "lookup1d",
             "vo_instance_norm_relu": "instnorm", "vo_conv3x3_winograd": "winograd", "vo_conv3x3_winograd4": "winograd4", "vo_conv5_winograd": "winograd1d",
-            "vo_conv3x3_bf16x3": "conv3x3_bf16x3", "vo_conv3x3s2_bf16x3": "conv3x3s2_bf16x3", "vo_conv7x7_bf16x3": "conv7x7_bf16x3",
+            "vo_conv3x3_bf16x3": "conv3x3_bf16x3", "vo_conv3x3s2_bf16x3": "conv3x3s2_bf16x3", "vo_conv3x3s2_shortcut_bf16x3": "conv3x3s2_bf16x3", "vo_conv7x7_bf16x3": "conv7x7_bf16x3",
             "vo_corr_volume_2d_bf16x3": "corr2d_bf16x3", "vo_corr_volume_1d_bf16x3": "corr1d_bf16x3",
             "vo_corr_volume_2d_presplit": "corr2d_presplit",
             "vo_instance_norm_apply": "instnorm_apply", "vo_conv1x1": "conv1x1"}

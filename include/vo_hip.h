@@ -187,6 +187,18 @@ int vo_conv5_bf16x3(const float* x, const void* arranged, float* y, int64_t y_ba
 int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
                         int N, int C, int H, int W, int K, void* stream);
+/* A downsampling residual block's two convolutions of its input in ONE pass (flow/flow_map_RAFT.py:42 and
+ * stereo/stereo_disparity_RAFT.py:46 construct the encoders whose stride-2 stages hold them): the 3x3 stride-2
+ * convolution (weights from vo_conv3x3_bf16x3_filter) and the 1x1 stride-2 projection shortcut (weights from
+ * vo_conv1x1_bf16x3_filter), K output channels each.  The shortcut's input samples x[2y][2x] are the 3x3 filter's centre
+ * tap, so the patch staged for the one serves the other: one more tap of matrix instructions per chunk instead of a second
+ * kernel that reads and stages x again.  Per output its own epilogue (scale / shift / ReLU, folded batch norm) or its own
+ * plane sums (stats, stats2: float64 (N,K,2), zeroed by the caller; no epilogue with them).  Needs an even W, an output
+ * width in multiples of 4 and 16-byte aligned outputs (dense (N,K,ceil(H/2),ceil(W/2))). */
+int vo_conv3x3s2_shortcut_bf16x3(const float* x, const void* arranged, const void* arranged1x1, float* y, float* y2,
+                                 const float* scale, const float* shift, int relu, double* stats,
+                                 const float* scale2, const float* shift2, int relu2, double* stats2,
+                                 int N, int C, int H, int W, int K, void* stream);
 /* The 1x1 stride-2 convolution of the residual stages' projection shortcuts on the same template (it reads
  * only the rows the stride lands on): weights (K,C) from vo_conv1x1_bf16x3_filter (ceil(K/64)*64 * C * 4 bytes),
  * epilogue or stats as vo_conv3x3s2_bf16x3. */

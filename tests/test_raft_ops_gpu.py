@@ -1035,6 +1035,39 @@ def test_split_bf16_conv1x1s2_matches_the_stock_convolution(vo, N, C, H, W, K):
     assert (stats - want_stats).abs().max().item() < 1e-4 * max(1.0, want_stats.abs().max().item())
 
 
+@pytest.mark.parametrize("N,C,H,W,K", [(2, 64, 48, 64, 96), (1, 96, 30, 40, 128), (2, 64, 37, 24, 64), (1, 128, 16, 48, 160)])
+def test_split_bf16_downsampling_pair_in_one_pass(vo, N, C, H, W, K):
+    """vo_conv3x3s2_shortcut_bf16x3 against its two single kernels (bit for bit: the same products in the same
+    order) and against the float64 stock convolutions: with plane sums for both outputs (the instance-norm
+    blocks), and with a scale / shift / ReLU store for the first and scale / shift for the second (the folded
+    batch norms); partial channel blocks and odd heights."""
+    import torch.nn.functional as Fn
+    from visual_odometry_amd import ops
+    x = _rand(N, C, H, W, seed=180).to(DEV)
+    w3 = (_rand(K, C, 3, 3, seed=181) / (3 * C ** 0.5)).to(DEV)
+    w1 = (_rand(K, C, 1, 1, seed=182) / C ** 0.5).to(DEV)
+    A3, A1 = ops.conv3x3_split_filter(w3), ops.conv1x1_split_filter(w1)
+    st3, st1 = (torch.zeros((N, K, 2), device=DEV, dtype=torch.float64) for _ in range(2))
+    y, sc = ops.conv3x3s2_shortcut_split(x, A3, A1, K, stats=st3, stats2=st1)
+    r3, r1 = (torch.zeros((N, K, 2), device=DEV, dtype=torch.float64) for _ in range(2))
+    assert torch.equal(y, ops.conv3x3s2_split(x, A3, K, stats=r3))
+    assert torch.equal(sc, ops.conv1x1s2_split(x, A1, K, stats=r1))
+    want3, want1 = Fn.conv2d(x.double(), w3.double(), None, 2, 1), Fn.conv2d(x.double(), w1.double(), None, 2, 0)
+    assert (y.double() - want3).abs().max().item() < SPLIT_TOL * max(1.0, want3.abs().max().item())
+    assert (sc.double() - want1).abs().max().item() < SPLIT_TOL * max(1.0, want1.abs().max().item())
+    for st, want in ((st3, want3), (st1, want1)):
+        sums = torch.stack([want.sum((2, 3)), (want * want).sum((2, 3))], dim=2)
+        assert (st - sums).abs().max().item() < 1e-4 * max(1.0, sums.abs().max().item())
+    s3, b3, s1, b1 = (_rand(K, seed=183 + i).to(DEV) for i in range(4))
+    y, sc = ops.conv3x3s2_shortcut_split(x, A3, A1, K, s3, b3, True, None, s1, b1, False, None)
+    assert torch.equal(y, ops.conv3x3s2_split(x, A3, K, s3, b3, True))
+    assert torch.equal(sc, ops.conv1x1s2_split(x, A1, K, s1, b1, False))
+    ref = torch.relu(want3.float() * s3[None, :, None, None] + b3[None, :, None, None])
+    assert (y - ref).abs().max().item() < 4 * SPLIT_TOL * max(1.0, ref.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.conv3x3s2_shortcut_split(x[:, :, :, :W - 2].contiguous() if (W - 2) // 2 % 4 else x[:, :, :, :W - 4].contiguous(), A3, A1, K)
+
+
 @pytest.mark.parametrize("N,C,H,W,K", [(1, 64, 5, 8, 64), (2, 336, 60, 80, 256), (2, 128, 33, 70, 100), (1, 256, 15, 20, 576),
                                        (2, 64, 9, 132, 144)])
 def test_split_bf16_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
@@ -1112,7 +1145,8 @@ def test_encoder_with_deferred_norms_matches_stock_operators(vo):
                 finally:
                     ops_recorder(old)
         assert "vo_instance_norm_relu" not in rec                   # no stand-alone statistics pass left
-        assert "vo_conv7x7_bf16x3" in rec and "vo_conv1x1s2_bf16x3" in rec
+        # the stems on the 7x7 kernel; the stride-2 blocks' 3x3 convolution and shortcut in one pass over their input
+        assert "vo_conv7x7_bf16x3" in rec and "vo_conv3x3s2_shortcut_bf16x3" in rec and "vo_conv1x1s2_bf16x3" not in rec
         assert (got - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item())
 
 

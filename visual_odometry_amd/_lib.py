@@ -36,6 +36,7 @@ SIGNATURES = {
     "vo_conv5_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv5_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv3x3s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "vo_conv3x3s2_shortcut_bf16x3": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_bf16x3_filter": [_P, _P, _I, _I, _P],
     "vo_conv1x1_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_pixel_major_bf16x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

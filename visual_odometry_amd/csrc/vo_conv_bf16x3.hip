@@ -122,16 +122,24 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 
 // MT: 32-channel tiles per workgroup (2: 64 output channels; 1: a last block of at most 32).
 // H, W: input size; Ho, Wo: output size.
-template <typename G, bool NORM_IN, int MT, bool GRU = false>
+// SHORT (3x3 stride 2 only): the residual block's projection shortcut, a 1x1 stride-2 convolution of the same input
+// with as many output channels, is computed beside the 3x3 one from the same staged patch: its sample x[2y][2x]
+// is the 3x3 filter's centre tap, so it costs one more tap of matrix instructions per chunk instead of a kernel
+// that stages the input a second time.  `sc` holds its weights (vo_conv1x1_bf16x3_filter), output and epilogue.
+struct Shortcut { const unsigned short* Ag; float* y; Epilogue ep; };
+
+template <typename G, bool NORM_IN, int MT, bool GRU = false, bool SHORT = false>
 __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
                                                             float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H,
                                                             int W, int Ho, int Wo, int K, int blocks_x, int blocks_y,
-                                                            int kblocks, int kb_base, GruEp gru) {
+                                                            int kblocks, int kb_base, GruEp gru, Shortcut sc) {
+    static_assert(!SHORT || (G::ST == 2 && G::TAPS == 9 && !NORM_IN && !GRU), "the fused shortcut belongs to the 3x3 stride-2 layer");
     constexpr int PLANE = G::PLANE, PC = G::PC, PR = G::PR, UNITS = G::UNITS, ROUNDS = G::ROUNDS, NTW = G::NTW;
     constexpr int A_CHUNK = G::A_CHUNK, A_PIECES = G::A_PIECES, TAPS = G::TAPS, STEPS = G::STEPS;
     // patch | weights of the chunk | (NORM_IN) per-channel scale and shift.  The reduction buffer of the
     // statistics epilogue re-uses the patch area after the last chunk.
-    __shared__ __align__(16) unsigned char lds[4 * PLANE + A_CHUNK + (NORM_IN ? G::MAX_NORM_C * 8 : 0)];
+    __shared__ __align__(16) unsigned char lds[4 * PLANE + A_CHUNK + (NORM_IN ? G::MAX_NORM_C * 8 : 0) + (SHORT ? A_TAP : 0)];
+    unsigned char* a2_lds = lds + 4 * PLANE + A_CHUNK;                       // SHORT: the shortcut's weights of the chunk
     float2* nrm = reinterpret_cast<float2*>(lds + 4 * PLANE + A_CHUNK);
     double* red = reinterpret_cast<double*>(lds);                            // [2][4 waves][64]
     static_assert(4 * PLANE >= 4 * 4096, "the epilogue's transposition slots and the reduction buffer do not fit the patch area");
@@ -154,6 +162,8 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, C * HW4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(Ag) + (int64_t)kb * nchunks * (A_CHUNK / 2), 0, nchunks * A_CHUNK, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(SHORT ? sc.Ag + (int64_t)kb * nchunks * (A_TAP / 2) : Ag), 0, SHORT ? nchunks * A_TAP : 0, 0x00020000);
     // GRU mode 2: the first gru.C input channels are read from `head` (dense, gru.C planes per image)
     const int head_chunks = (GRU && gru.head) ? gru.C / CK : 0;
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -240,6 +250,16 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
 
+    f32x16 acc2[SHORT ? MT : 1][SHORT ? NTW : 1];
+    if (SHORT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[mt][nt][e] = 0.0f;
+    }
+
     // A fragment of (tap, part, mt): weights area + ((tap*2 + part)*2 + mt) KiB + 16*lane
     // B fragment of (tap r, s), pixel tile nt: patch row (NTW*wave + nt)*stride + r, patch column (lane & 31)*stride + s + slack
     const unsigned char* a_lds = lds + 4 * PLANE + lane * 16;
@@ -257,13 +277,15 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     // a chunk's weights are a linear copy (they are stored in operand order); they are requested at the
     // end of the previous chunk's multiply phase, so their latency passes under the barrier and the
     // conversion of the patch
-    u32x4 aw[A_PIECES];
+    u32x4 aw[A_PIECES], aw2;
+    static_assert(A_TAP == NT * 16, "the shortcut's weights of a chunk are one 16-byte piece per thread");
     auto load_aw = [&](int chunk) {
         chunk = chunk < nchunks ? chunk : nchunks - 1;
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i)
             if ((i + 1) * NT * 16 <= A_CHUNK || (tid + i * NT) * 16 < A_CHUNK)
                 aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ars, (tid + i * NT) * 16, chunk * A_CHUNK, 0);
+        if (SHORT) aw2 = __builtin_amdgcn_raw_buffer_load_b128(ars2, tid * 16, chunk * A_TAP, 0);
     };
     load_raw(0);
     load_aw(0);
@@ -274,6 +296,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         for (int i = 0; i < A_PIECES; ++i)
             if ((i + 1) * NT * 16 <= A_CHUNK || (tid + i * NT) * 16 < A_CHUNK)
                 *reinterpret_cast<u32x4*>(lds + 4 * PLANE + (tid + i * NT) * 16) = aw[i];
+        if (SHORT) *reinterpret_cast<u32x4*>(a2_lds + tid * 16) = aw2;
         __syncthreads();
         load_raw(chunk + 1);                                                 // in flight during the whole multiply phase
 
@@ -306,10 +329,28 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][1], acc[mt][nt], 0, 0, 0);
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
             }
-            // the step's reads first (they feed the NEXT step), then its matrix instructions
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 + A_PER_STEP, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (SHORT && tap == 4) {
+                // the centre tap's B fragments are the shortcut's input samples
+                bf16x8 f2[2][MT];
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) f2[part][mt] = *reinterpret_cast<const bf16x8*>(a2_lds + lane * 16 + (part * 2 + mt) * 1024);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[1][mt], fb[cb][0], acc2[mt][nt], 0, 0, 0);
+                    acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[0][mt], fb[cb][1], acc2[mt][nt], 0, 0, 0);
+                    acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[0][mt], fb[cb][0], acc2[mt][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + A_PER_STEP + 2 * MT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // the step's reads first (they feed the NEXT step), then its matrix instructions
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + A_PER_STEP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         load_aw(chunk + 1);
         __syncthreads();                                                     // everyone has read the patch and the weights
@@ -506,6 +547,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     // Plane sums ride along: a lane adds up the pixels it stores (float32 over its 16 pixels of a channel),
     // the eight lanes that share a channel row combine in float64, the four waves through LDS.
     if (wide) {
+      auto wide_store = [&](auto& acc, const Epilogue& ep, const __amdgpu_buffer_rsrc_t& yrs, const __amdgpu_buffer_rsrc_t& srs) {
         float* slot = reinterpret_cast<float*>(lds) + wave * 1024;
         double* redw = reinterpret_cast<double*>(lds + 4 * 4096);            // [2][4 waves][64], behind the four slots
         static_assert(4 * PLANE + A_CHUNK >= 4 * 4096 + 2 * 4 * 64 * 8, "no room for the reduction buffer behind the slots");
@@ -578,6 +620,17 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 const int k = kb * KB + krow;
                 if (k < K) atomicAdd(ep.stats + ((int64_t)n * K + k) * 2 + which, tot);
             }
+        }
+      };
+        wide_store(acc, ep, yrs, srs);
+        if constexpr (SHORT) {
+            // the shortcut's tile: same path, its own output, epilogue and sums (the slots and the reduction
+            // buffer are free again once every wave is through the first store)
+            __syncthreads();
+            float* y2n = sc.y + (int64_t)n * sc.ep.y_batch_stride;
+            const __amdgpu_buffer_rsrc_t yrs2 = __builtin_amdgcn_make_buffer_rsrc(y2n, 0, K * HWo4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t srs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0, 0x00020000);
+            wide_store(acc2, sc.ep, yrs2, srs2);
         }
         return;
     }
@@ -673,13 +726,13 @@ int launch_conv(const char* name, const float* x, const void* arranged, float* y
     const int full = (rem >= 1 && rem <= 32 && G::ST == 1) ? kblocks - 1 : kblocks;
     if (full > 0) {
         const dim3 grid((unsigned)(blocks * full));
-        if (in_stats) conv_bf16x3_kernel<G, true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0, GruEp{});
-        else conv_bf16x3_kernel<G, false, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0, GruEp{});
+        if (in_stats) conv_bf16x3_kernel<G, true, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0, GruEp{}, Shortcut{});
+        else conv_bf16x3_kernel<G, false, 2><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, full, 0, GruEp{}, Shortcut{});
     }
     if (full < kblocks) {
         const dim3 grid((unsigned)blocks);
-        if (in_stats) conv_bf16x3_kernel<G, true, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full, GruEp{});
-        else conv_bf16x3_kernel<G, false, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full, GruEp{});
+        if (in_stats) conv_bf16x3_kernel<G, true, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full, GruEp{}, Shortcut{});
+        else conv_bf16x3_kernel<G, false, 1><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, nrm, C, H, W, Ho, Wo, K, bx, by, 1, full, GruEp{}, Shortcut{});
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
@@ -703,6 +756,40 @@ inline bool narrow_blocks_fit_better(int H, int W) {
 using Geo3x3s2 = Geo<3, 3, 2, 1>;
 using Geo1x1s2 = Geo<1, 1, 2, 1>;
 
+// The 3x3 stride-2 convolution of a downsampling residual block together with the block's 1x1 stride-2 projection
+// shortcut (same input, same number of output channels), each with its own epilogue or plane sums.
+int launch_conv_shortcut(const char* name, const float* x, const void* arranged, const void* arranged1x1, float* y, float* y2,
+                         const float* scale, const float* shift, int relu, double* stats, const float* scale2, const float* shift2,
+                         int relu2, double* stats2, int N, int C, int H, int W, int K, hipStream_t st) {
+    using G = Geo3x3s2;
+    if (!x || !arranged || !arranged1x1 || !y || !y2) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if ((scale && !shift) || (scale2 && !shift2)) return vo_fail(VO_ERR_INVALID_ARG, "%s: scale without shift", name);
+    if ((stats && (shift || relu)) || (stats2 && (shift2 || relu2)))
+        return vo_fail(VO_ERR_INVALID_ARG, "%s: statistics are of the raw output, no epilogue with them", name);
+    if (y == y2) return vo_fail(VO_ERR_INVALID_ARG, "%s: the two outputs must differ", name);
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes", name);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (C % CK != 0) return vo_fail(VO_ERR_UNSUPPORTED, "%s: C=%d is not a multiple of %d", name, C, CK);
+    if (W % 2 != 0 || (reinterpret_cast<uintptr_t>(x) & 7) != 0)
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: needs an even width and an 8-byte aligned input (W=%d)", name, W);
+    if (Wo % 4 != 0 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y2)) & 15) != 0)
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: needs an output width in multiples of 4 and 16-byte aligned outputs (Wo=%d)", name, Wo);
+    if ((int64_t)C * H * W * 4 >= 0x7fffffffLL || (int64_t)K * Ho * Wo * 4 >= 0x7fffffffLL)
+        return vo_fail(VO_ERR_UNSUPPORTED, "%s: one image of the input or output exceeds 2 GiB", name);
+    const int bx = (Wo + G::TW - 1) / G::TW, by = (Ho + G::TH - 1) / G::TH;
+    const int kblocks = (K + KB - 1) / KB;
+    const int64_t blocks = (int64_t)bx * by * N * kblocks;
+    if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
+    const int64_t ybs = (int64_t)K * Ho * Wo;
+    const Epilogue ep{scale, shift, nullptr, relu, ybs, stats, 0};
+    const Shortcut sc{static_cast<const unsigned short*>(arranged1x1), y2, Epilogue{scale2, shift2, nullptr, relu2, ybs, stats2, 0}};
+    conv_bf16x3_kernel<G, false, 2, false, true><<<dim3((unsigned)blocks), dim3(NT), 0, st>>>(
+        x, static_cast<const unsigned short*>(arranged), y, ep, InputNorm{nullptr, 0.0f}, C, H, W, Ho, Wo, K, bx, by, kblocks, 0, GruEp{}, sc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
+    return VO_OK;
+}
+
 // GRU convolutions: shape 0 = 3x3 (padding 1), 1 = 1x5 (padding (0,2)), 2 = 5x1 (padding (2,0)); K output channels
 // in blocks of 64, gate arithmetic in the store (16-byte path).
 template <typename G>
@@ -713,7 +800,7 @@ int launch_gru(const char* name, const float* x, const unsigned short* ag, float
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
     const Epilogue ep{nullptr, shift, nullptr, 0, y_batch_stride, nullptr, 0};
     conv_bf16x3_kernel<G, false, 2, true><<<dim3((unsigned)blocks), dim3(NT), 0, st>>>(x, ag, y, ep, InputNorm{nullptr, 0.0f}, C, H, W, H, W, K,
-                                                                                     bx, by, kblocks, 0, gru);
+                                                                                     bx, by, kblocks, 0, gru, Shortcut{});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;
@@ -784,6 +871,14 @@ extern "C" int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* 
                                    int relu, double* stats, int N, int C, int H, int W, int K, void* stream) {
     return launch_conv<Geo3x3s2>("vo_conv3x3s2_bf16x3", x, arranged, y, 0, scale, shift, relu, nullptr, stats, nullptr, 0.0f, N, C,
                                  H, W, K, vo_stream(stream));
+}
+
+extern "C" int vo_conv3x3s2_shortcut_bf16x3(const float* x, const void* arranged, const void* arranged1x1, float* y, float* y2,
+                                            const float* scale, const float* shift, int relu, double* stats,
+                                            const float* scale2, const float* shift2, int relu2, double* stats2,
+                                            int N, int C, int H, int W, int K, void* stream) {
+    return launch_conv_shortcut("vo_conv3x3s2_shortcut_bf16x3", x, arranged, arranged1x1, y, y2, scale, shift, relu, stats, scale2, shift2,
+                                relu2, stats2, N, C, H, W, K, vo_stream(stream));
 }
 
 extern "C" int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream) {

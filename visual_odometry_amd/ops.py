@@ -447,6 +447,37 @@ def conv1x1_pixel_major_split(x: torch.Tensor, arranged: torch.Tensor, K: int, s
     return out
 
 
+def conv3x3s2_shortcut_split(x: torch.Tensor, arranged: torch.Tensor, arranged1x1: torch.Tensor, K: int,
+                             scale: torch.Tensor | None = None, shift: torch.Tensor | None = None, relu: bool = False,
+                             stats: torch.Tensor | None = None, scale2: torch.Tensor | None = None,
+                             shift2: torch.Tensor | None = None, relu2: bool = False, stats2: torch.Tensor | None = None):
+    """A downsampling residual block's 3x3 stride-2 convolution (padding 1) and its 1x1 stride-2 projection shortcut in
+    ONE pass over x (N,C,H,W) float32: the shortcut's input samples are the 3x3 filter's centre tap, so the staged
+    patch serves both.  Weights from conv3x3_split_filter and conv1x1_split_filter, K output channels each; per
+    output scale / shift / relu, or ``stats`` (N,K,2) float64 that receive the raw output's plane sums.  Needs an
+    output width in multiples of 4.  Returns (y, shortcut), both (N,K,ceil(H/2),ceil(W/2))."""
+    N, C, H, W = x.shape
+    if arranged.numel() != (K + 63) // 64 * 64 * C * 9 or arranged1x1.numel() != (K + 63) // 64 * 64 * C:
+        raise ValueError("arranged weights do not match (K, C)")
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    if W % 2 or Wo % 4:
+        raise ValueError("the fused stride-2 kernel needs an even width and an output width in multiples of 4")
+    for t, name in ((scale, "scale"), (shift, "shift"), (scale2, "scale2"), (shift2, "shift2")):
+        if t is not None and t.numel() != K:
+            raise ValueError(f"{name} must have one entry per output channel")
+    for t, name in ((stats, "stats"), (stats2, "stats2")):
+        if t is not None and (tuple(t.shape) != (N, K, 2) or t.dtype != torch.float64):
+            raise ValueError(f"{name} must be a float64 (N,K,2) tensor")
+    y = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
+    y2 = torch.empty_like(y)
+    _call("vo_conv3x3s2_shortcut_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32),
+          _dev(arranged1x1, "shortcut weights", torch.float32), y.data_ptr(), y2.data_ptr(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), _opt(stats, "stats", torch.float64),
+          _opt(scale2, "scale2", torch.float32), _opt(shift2, "shift2", torch.float32), int(relu2), _opt(stats2, "stats2", torch.float64),
+          N, C, H, W, K, _stream(), nbytes=4 * (x.numel() + 2 * y.numel()), flops=2 * 3 * N * K * C * Ho * Wo * 10)
+    return y, y2
+
+
 def conv1x1s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
                     shift: torch.Tensor | None = None, relu: bool = False, stats: torch.Tensor | None = None) -> torch.Tensor:
     """conv2d(x, weight(K,C,1,1), stride=2) on the split-bf16 direct kernel (weights from

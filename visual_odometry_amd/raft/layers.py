@@ -591,6 +591,14 @@ def _norm(kind: str, planes: int) -> nn.Module:
     raise ValueError(f"unknown norm '{kind}'")
 
 
+def _shortcut_fuses(x: torch.Tensor, conv3x3: nn.Conv2d, conv1x1: nn.Conv2d) -> bool:
+    """True when a stride-2 block's 3x3 convolution and its projection shortcut can share one pass over x
+    (ops.conv3x3s2_shortcut_split): same widths, an output width in multiples of 4, the split-bf16 arithmetic."""
+    Wo = (x.shape[3] + 1) // 2
+    return (split_bf16_on() and x.is_contiguous() and conv3x3.out_channels == conv1x1.out_channels and x.shape[3] % 2 == 0
+            and Wo % 4 == 0 and conv3x3.stride == (2, 2) and conv1x1.stride == (2, 2))
+
+
 class ResidualBlock(nn.Module):
     """Two 3x3 convs with a (strided 1x1) skip; the skip conv exists whenever the
     block changes resolution or width."""
@@ -615,10 +623,31 @@ class ResidualBlock(nn.Module):
             return chained
         if isinstance(x, RawNorm):
             x = x.tensor()
-        y = conv_norm_act(x, self.conv1, self.norm1, True)
-        if self.downsample is not None:
-            x = conv_norm_act(x, self.downsample[0], self.norm3, False)
+        fused = self._batch_norm_downsampling_pair(x)
+        if fused is not None:
+            y, x = fused
+        else:
+            y = conv_norm_act(x, self.conv1, self.norm1, True)
+            if self.downsample is not None:
+                x = conv_norm_act(x, self.downsample[0], self.norm3, False)
         return conv_norm_act(y, self.conv2, self.norm2, True, skip=x)        # relu(x + relu(norm2(conv2(y))))
+
+    def _batch_norm_downsampling_pair(self, x):
+        """(relu(norm1(conv1(x))), norm3(shortcut(x))) of a stride-2 block with inference batch norms from ONE
+        pass over x (the norms folded into the two stores), or None where that kernel does not apply."""
+        if self.downsample is None or not (_fusable(x) and x.dtype == torch.float32):
+            return None
+        bn = lambda n: isinstance(n, nn.BatchNorm2d) and not n.training and n.track_running_stats
+        c1, d = self.conv1, self.downsample[0]
+        if not (bn(self.norm1) and bn(self.norm3) and _shortcut_fuses(x, c1, d)):
+            return None
+        Us = _split_s2_weights_for(x, c1.weight, c1.stride, c1.padding, c1.dilation, c1.groups)
+        Ws = _conv1x1s2_split_weights_for(x, d.weight, d.stride, d.padding, d.dilation, d.groups)
+        if Us is None or Ws is None:
+            return None
+        s1, b1 = _folded_batch_norm(self.norm1, c1.bias)
+        s3, b3 = _folded_batch_norm(self.norm3, d.bias)
+        return ops.conv3x3s2_shortcut_split(x, Us, Ws, c1.out_channels, s1, b1, True, None, s3, b3, False, None)
 
     def _instance_norm_chain(self, x):
         """Both 3x3 convolutions on the matrix-core kernels with instance norm: conv1's store leaves
@@ -655,9 +684,13 @@ class ResidualBlock(nn.Module):
             Ws = _conv1x1s2_split_weights_for(xt, d.weight, d.stride, d.padding, d.dilation, d.groups)
             if Us is None or Ws is None:
                 return None
-            y1 = ops.conv3x3s2_split(xt, Us, c1.out_channels, stats=st1)
             skip_stats = torch.zeros((xt.shape[0], d.out_channels, 2), device=xt.device, dtype=torch.float64)
-            skip = ops.conv1x1s2_split(xt, Ws, d.out_channels, stats=skip_stats)
+            if _shortcut_fuses(xt, c1, d):
+                # one pass over the block's input: the shortcut's samples are the 3x3 filter's centre tap
+                y1, skip = ops.conv3x3s2_shortcut_split(xt, Us, Ws, c1.out_channels, stats=st1, stats2=skip_stats)
+            else:
+                y1 = ops.conv3x3s2_split(xt, Us, c1.out_channels, stats=st1)
+                skip = ops.conv1x1s2_split(xt, Ws, d.out_channels, stats=skip_stats)
             skip_eps, skip_relu = self.norm3.eps, False
         U2 = _winograd_filter_for(y1, c2.weight, c2.stride, c2.padding, c2.dilation, c2.groups)
         if U2 is None:
