@@ -20,9 +20,9 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 for n, v in d.most_common(top):
     print(f"{v / 1e6:8.2f} ms {100 * v / tot:5.1f}% x{c[n]:4d}  {n}")
 
-groups = [("vo_conv3x3_bf16x3", r"conv_bf16x3_kernel<.*Geo<3, 3, 1, 4, (32|16)>, (true|false), [12], false>"),
-          ("vo_gru_conv_zr/q_bf16x3", r"conv_bf16x3_kernel<.*Geo<.*>, false, 2, true>"),
-          ("vo_conv5_bf16x3", r"conv_bf16x3_kernel<.*Geo<(1, 5|5, 1), 1, 4, (32|16)>, (true|false), [12], false>"),
+groups = [("vo_conv3x3_bf16x3", r"conv_bf16x3_kernel<.*Geo<3, 3, 1, 4, (32|16)>, (true|false), [12], false, false>"),
+          ("vo_gru_conv_zr/q_bf16x3", r"conv_bf16x3_kernel<.*Geo<.*>, false, 2, true, false>"),
+          ("vo_conv5_bf16x3", r"conv_bf16x3_kernel<.*Geo<(1, 5|5, 1), 1, 4, (32|16)>, (true|false), [12], false, false>"),
           ("vo_conv3x3s2[_shortcut]_bf16x3", r"conv_bf16x3_kernel<.*Geo<3, 3, 2"), ("vo_conv1x1s2_bf16x3", r"conv_bf16x3_kernel<.*Geo<1, 1, 2"),
           ("vo_conv1x1[_pixel_major]_bf16x3", r"conv_bf16x3_kernel<.*Geo<1, 1, 1"), ("vo_conv7x7_bf16x3", r"conv7_split_kernel"),
           ("vo_conv1x1 / _pixel_major / taps", r"conv1x1_kernel"), ("vo_instance_norm_apply", r"instnorm_apply_kernel"),
