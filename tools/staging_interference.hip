@@ -233,6 +233,104 @@ int run_alt(const unsigned* src, const float* gx, float* out, int chunks, int bl
     return 0;
 }
 
+// A variant of the production structure for layers with 128 or more output channels: ONE workgroup of 8 waves per CU,
+// waves 0-3 and 4-7 multiply the same staged patch by the weights of two channel blocks (72 KiB of weights per chunk),
+// all 8 waves share the staging of the patch (half the conversions and stores per lane).
+__global__ __launch_bounds__(512, 1) void dual_block(const unsigned* src, const float* gx, float* out, int chunks, int stage) {
+    extern __shared__ __align__(16) unsigned char lds[];                  // patch | weights of block 0 | weights of block 1
+    for (int i = threadIdx.x; i < LDS / 4; i += 512) reinterpret_cast<unsigned*>(lds)[i] = src[i];
+    for (int i = threadIdx.x; i < WEIGHTS / 4; i += 512) reinterpret_cast<unsigned*>(lds + LDS)[i] = src[PATCH / 4 + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = threadIdx.x, half = wave >> 2, w4 = wave & 3;
+    const unsigned char* a_lds = lds + PATCH + half * WEIGHTS + lane * 16;
+    const unsigned char* b_lds = lds + (lane >> 5) * PL + ((4 * w4) * 36 + (lane & 31)) * 16;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx) + (size_t)(blockIdx.x & 255) * 131072, 0, 131072 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(src), 0, LDS, 0x00020000);
+    f32x16 acc[2][4];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+    u32x2 rv[2][8];                      // 648 units over 512 lanes: 2 rounds
+    u32x4 aw[9];
+    auto load_raw = [&](int c) {
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 8; ++j)
+            rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (t + i * 512) * 8, ((c & 3) * 8 + j) * 6144, 0);
+    };
+    auto load_aw = [&](int c) {
+        for (int i = 0; i < 9; ++i) aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ws, ((t & 255) + i * 256) * 16, PATCH, 0);
+    };
+    load_raw(0); load_aw(0);
+    for (int c = 0; c < chunks; ++c) {
+        if (stage) {
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && t >= 136) continue;
+                for (int px = 0; px < 2; ++px) {
+                    u32x4 hi, lo;
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float a = __uint_as_float(rv[i][2 * jj][px]), b = __uint_as_float(rv[i][2 * jj + 1][px]);
+                        const unsigned h = pack_bf16(a, b);
+                        hi[jj] = h;
+                        lo[jj] = pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+                    }
+                    const int u = i * 512 + t, kg = u / 324, rem = u - kg * 324;
+                    *reinterpret_cast<u32x4*>(lds + kg * PL + (rem * 2 + px) * 16) = hi;
+                    *reinterpret_cast<u32x4*>(lds + 2 * PL + kg * PL + (rem * 2 + px) * 16) = lo;
+                }
+            }
+            for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(lds + PATCH + half * WEIGHTS + ((t & 255) + i * 256) * 16) = aw[i];
+        }
+        __syncthreads();
+        if (stage) load_raw(c + 1);
+        {
+            bf16x8 fa[2][2][2], fb[2][2];
+            for (int part = 0; part < 2; ++part) {
+                for (int mt = 0; mt < 2; ++mt) fa[0][part][mt] = *reinterpret_cast<const bf16x8*>(a_lds + (part * 2 + mt) * 1024);
+                fb[0][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL);
+            }
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+                const int tap = st / 4, nt = st % 4, ca = tap & 1, cb = st & 1;
+                if (st + 1 < 36) {
+                    const int t2 = (st + 1) / 4, n2 = (st + 1) % 4;
+                    for (int part = 0; part < 2; ++part)
+                        fb[cb ^ 1][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL + ((n2 + t2 / 3) * 36 + t2 % 3) * 16);
+                }
+                if (tap + 1 < 9) { const int f = nt; fa[ca ^ 1][f / 2][f % 2] = *reinterpret_cast<const bf16x8*>(a_lds + (((tap + 1) * 2 + f / 2) * 2 + f % 2) * 1024); }
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][1][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (stage) load_aw(c + 1);
+        __syncthreads();
+    }
+    float s = 0;
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) s += acc[m][n][e];
+    for (int i = 0; i < 2; ++i) s += __uint_as_float(rv[i][0][0]);
+    s += __uint_as_float(aw[0][0]);
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+int run_dual(const unsigned* src, const float* gx, float* out, int chunks, int stage) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    const int lds = LDS + WEIGHTS;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dual_block), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        (void)hipEventRecord(e0);
+        dual_block<<<256, 512, lds>>>(src, gx, out, chunks, stage);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    const double flops = 2.0 * 216 * 32 * 32 * 16 * 8.0 * 256 * chunks;
+    printf("two channel blocks per workgroup (8 waves, one workgroup per CU), staging %s: %.3f ms, %.0f TFLOP/s\n", stage ? "on" : "off", best, flops / best / 1e9);
+    return 0;
+}
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int MODE>
@@ -267,6 +365,7 @@ int main() {
     CHECK(hipMemcpy(src, h.data(), LDS, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(gx, g.data(), g.size() * 4, hipMemcpyHostToDevice));
     const int chunks = 400;
+    for (int round = 0; round < 2; ++round) if (run_dual(src, gx, out, chunks, 0) || run_dual(src, gx, out, chunks, 1)) return 1;
     for (int blocks = 256; blocks <= 512; blocks += 256)
         for (int round = 0; round < 1; ++round)
             if (run_alt<2>(src, gx, out, chunks, blocks) || run_alt<1>(src, gx, out, chunks, blocks) || run_alt<3>(src, gx, out, chunks, blocks) ||
