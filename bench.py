@@ -520,6 +520,18 @@ def main():
             out["reference_driver_settings"] = config_leg(
                 lambda: make_vo(False, "full", 16, "ransac"), left, right, legs_steps,
                 f"RAFT-Flow + RAFT-Stereo(full args) {W}x{H}, 16 iters, RANSAC pose (1000 hypotheses per pair)")
+            # BASELINE config 4: 1280x720 with the dense grid (max_number=20000 -> 19 928 keypoints), realtime arguments;
+            # the flow volume is 14400^2 floats = 829 MB per pair, so a step holds 16 pairs
+            Bh = 16
+            lh, rh = syn.stereo_sequence(seed=300, frames=Bh + 1, h=720, w=1280)
+            lh, rh = torch.from_numpy(lh).cuda(), torch.from_numpy(rh).cuda()
+            cfg_h = VOConfig(iters=args.iters, stereo=RAFTStereoConfig.realtime(), max_keypoints=20000,
+                             camera_offset=syn.CAMERA_OFFSET)
+            torch.cuda.reset_peak_memory_stats()
+            out["high_resolution"] = config_leg(
+                lambda: VisualOdometry(cfg_h, syn.left_K(2.0), syn.focal_length_px() * 2.0, syn.baseline(), np.ones((720, 1280), bool), seed=0),
+                lh, rh, legs_steps, f"RAFT-Flow + RAFT-Stereo(realtime args) 1280x720, {args.iters} iters, 19928 grid keypoints, Kabsch pose")
+            del lh, rh
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
