@@ -110,6 +110,29 @@ def test_virtual_shards_equal_the_unsharded_run(vo, pose):
         assert err3 < 1e-4, err3
 
 
+def test_eight_virtual_shards_at_full_size(vo):
+    """The 8-rank partition of a 640x480 sequence (full RAFT-Stereo arguments, 12 iterations, RANSAC pose as the
+    reference's driver runs it), the ranks' shards run one after the other on this GPU: every rank recomputes its
+    halo frame's depth, 19 pairs split 3,3,3,3,3,3,1,0, and the gathered rows compose into the unsharded trajectory.
+    At this size every convolution is a hand-written kernel whose per-image result does not depend on the batch."""
+    from visual_odometry_amd.pipeline import compose_trajectory, shard_pairs
+    from visual_odometry_amd.raft.models import RAFTStereoConfig
+    H, W, F = 480, 640, 20
+    pipe = _vo(H, W, iters=12, n_kp=320, pose="ransac", stereo=RAFTStereoConfig())
+    left, right = syn.stereo_sequence(23, F, H, W)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    T_all, sk_all = pipe.run(l, r, chunk_pairs=F - 1)
+    parts = [pipe.run_shard(l, r, rank, 8, chunk_pairs=2) for rank in range(8)]
+    assert [(p[0], p[1]) for p in parts] == [shard_pairs(F - 1, rank, 8) for rank in range(8)]
+    assert [p[2].shape[0] for p in parts] == [3, 3, 3, 3, 3, 3, 1, 0]
+    T_s, sk_s = torch.cat([p[2] for p in parts]), torch.cat([p[3] for p in parts])
+    assert torch.equal(sk_all, sk_s) and not bool(sk_all.any())
+    assert (T_all - T_s).abs().max().item() < 1e-6
+    Ga = compose_trajectory(T_all.cpu().numpy(), sk_all.cpu().numpy())
+    Gs = compose_trajectory(T_s.cpu().numpy(), sk_s.cpu().numpy())
+    assert np.abs(Gs - Ga).max() < 1e-5
+
+
 def test_host_frames_are_uploaded_chunk_by_chunk(vo):
     """Pinned host frames go up on a second stream, one chunk ahead of the computation; the
     poses equal those from frames already resident in HBM bit for bit."""
