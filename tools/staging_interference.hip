@@ -11,9 +11,11 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void roles(const unsigned* src, const float
 // a component: bit 2 = no conversions, bit 3 = no copy of the weights, bit 4 = no LDS stores of the patch, bit 5 = no global loads;
 // bit 6 = the global loads issued one per (tap, pixel tile) step of the multiply phase instead of in two bursts.
 template <int PARTS>
-__global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const float* gx, float* out, int chunks) {
+__global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const float* gx, float* out, int chunks, const float* big, float* bigout, unsigned big_units) {
     extern __shared__ __align__(16) unsigned char lds[];
     for (int i = threadIdx.x; i < LDS / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = src[i];
     __syncthreads();
@@ -144,6 +146,15 @@ __global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const
     u32x2 rv[3][8];
     u32x4 aw[9];
     auto load_raw = [&](int c) {
+        if (PARTS & 128) {
+            // bit 7: every chunk's patch comes from memory nobody has touched (48 KiB units of a buffer far larger
+            // than the caches), as a layer's input does
+            const unsigned unit = (blockIdx.x * 131u + (unsigned)c * 7919u) % big_units;
+            const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(big) + (size_t)unit * 12288, 0, 49152, 0x00020000);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j)
+                rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(hs, (t + i * 256) * 8 + j * 6144, 0, 0);
+            return;
+        }
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j)
             rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (t + i * 256) * 8, ((c & 3) * 8 + j) * 6144, 0);
     };
@@ -152,6 +163,15 @@ __global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const
     };
     load_raw(0); load_aw(0);
     for (int c = 0; c < chunks; ++c) {
+        if ((PARTS & 256) && (c & 7) == 7) {
+            // bit 8: every 8 chunks the tile leaves: 128 KiB per workgroup, 16-byte stores, to memory of its own
+            const unsigned unit = (blockIdx.x * 977u + (unsigned)(c >> 3) * 4099u) % (big_units / 3);
+            float* dst = bigout + (size_t)unit * 32768;
+            for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = {acc[m][n][4 * q4], acc[m][n][4 * q4 + 1], acc[m][n][4 * q4 + 2], acc[m][n][4 * q4 + 3]};
+                *reinterpret_cast<f32x4*>(dst + ((m * 4 + n) * 4 + q4) * 1024 + t * 4) = v;
+            }
+        }
         if (PARTS & 1) {
             for (int i = 0; i < 3; ++i) {
                 if (i == 2 && t >= 136) continue;                    // 648 units over 256 lanes
@@ -215,14 +235,14 @@ __global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const
 }
 
 template <int PARTS>
-int run_alt(const unsigned* src, const float* gx, float* out, int chunks, int blocks) {
+int run_alt(const unsigned* src, const float* gx, float* out, int chunks, int blocks, const float* big = nullptr, float* bigout = nullptr, unsigned big_units = 1) {
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(alternating<PARTS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return 1;
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        alternating<PARTS><<<blocks, 256, LDS>>>(src, gx, out, chunks);
+        alternating<PARTS><<<blocks, 256, LDS>>>(src, gx, out, chunks, big, bigout, big_units);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -365,6 +385,20 @@ int main() {
     CHECK(hipMemcpy(src, h.data(), LDS, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(gx, g.data(), g.size() * 4, hipMemcpyHostToDevice));
     const int chunks = 400;
+    {
+        const unsigned big_units = 65536;                              // 65536 x 48 KiB = 3 GiB of input
+        float *big = nullptr, *bigout = nullptr;
+        CHECK(hipMalloc(&big, (size_t)big_units * 49152)); CHECK(hipMalloc(&bigout, (size_t)(big_units / 3) * 131072));
+        // random values everywhere (constant operands would let the chip hold a higher clock): copies of gx
+        for (size_t off = 0; off < (size_t)big_units * 49152; off += g.size() * 4) {
+            const size_t nbytes = std::min(g.size() * 4, (size_t)big_units * 49152 - off);
+            CHECK(hipMemcpy(reinterpret_cast<char*>(big) + off, gx, nbytes, hipMemcpyDeviceToDevice));
+        }
+        for (int round = 0; round < 2; ++round)
+            if (run_alt<3>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 128>(src, gx, out, chunks, 512, big, bigout, big_units) ||
+                run_alt<3 + 256>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 128 + 256>(src, gx, out, chunks, 512, big, bigout, big_units)) return 1;
+        CHECK(hipFree(big)); CHECK(hipFree(bigout));
+    }
     for (int round = 0; round < 2; ++round) if (run_dual(src, gx, out, chunks, 0) || run_dual(src, gx, out, chunks, 1)) return 1;
     for (int blocks = 256; blocks <= 512; blocks += 256)
         for (int round = 0; round < 1; ++round)
