@@ -351,6 +351,180 @@ int run_dual(const unsigned* src, const float* gx, float* out, int chunks, int s
     return 0;
 }
 
+// A design probe for a hand-over WITHOUT a workgroup barrier: 8 waves per CU, waves 4-7 stage chunk c+1 into one of
+// two LDS buffers (patch and weights) while waves 0-3 multiply chunk c out of the other; LDS counters say when a
+// buffer is filled (4 staging waves) and when it is free again (4 multiplying waves).  A wave waits by polling its
+// counter (bounded: after SPIN_LIMIT polls it gives up and flags the run as failed, so a slip in the protocol cannot
+// hang the GPU).  MEM: bit 0 = every chunk's patch from memory in no cache, bit 1 = the multiplying waves store a
+// 128 KiB tile every 8 chunks.
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+template <int MEM>
+__global__ __launch_bounds__(512, 1) void handoff(const unsigned* src, const float* gx, float* out, int chunks, const float* big,
+                                                  float* bigout, unsigned big_units, int* failed, long long* clocks) {
+    extern __shared__ __align__(16) unsigned char lds[];                  // 2 x (patch | weights) | counters
+    unsigned* cnt = reinterpret_cast<unsigned*>(lds + 2 * LDS);           // filled[2], freed[2]
+    for (int i = threadIdx.x; i < LDS / 4; i += 512) { reinterpret_cast<unsigned*>(lds)[i] = src[i]; reinterpret_cast<unsigned*>(lds + LDS)[i] = src[i]; }
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto wait_for = [&](unsigned* c, unsigned target) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+            if (++spins > SPIN_LIMIT) { if (lane == 0) atomicExch(failed, 1); return false; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");          // LDS serves one wave's requests in order: nothing else is needed
+        return true;
+    };
+    if (wave < 4) {
+        f32x16 acc[2][4];
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+        const unsigned char* a_lds0 = lds + PATCH + lane * 16;
+        const unsigned char* b_lds0 = lds + (lane >> 5) * PL + ((4 * wave) * 36 + (lane & 31)) * 16;
+        bool ok = true;
+        long long waited = 0;
+        const long long begun = clock64();
+        for (int c = 0; c < chunks && ok; ++c) {
+            const int b = c & 1;
+            const long long t0 = clock64();
+            ok = wait_for(cnt + b, 4u * ((unsigned)(c >> 1) + 1u));
+            const long long t1m = clock64();
+            waited += t1m - t0;
+            if (blockIdx.x == 0 && threadIdx.x < 256 && lane == 0 && c >= 100 && c < 104) { clocks[8 + (c - 100) * 16 + wave * 2] = t0; clocks[8 + (c - 100) * 16 + wave * 2 + 1] = t1m; }
+            const unsigned char* a_lds = a_lds0 + b * LDS;
+            const unsigned char* b_lds = b_lds0 + b * LDS;
+            bf16x8 fa[2][2][2], fb[2][2];
+            for (int part = 0; part < 2; ++part) {
+                for (int mt = 0; mt < 2; ++mt) fa[0][part][mt] = *reinterpret_cast<const bf16x8*>(a_lds + (part * 2 + mt) * 1024);
+                fb[0][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL);
+            }
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+                const int tap = st / 4, nt = st % 4, ca = tap & 1, cb = st & 1;
+                if (st + 1 < 36) {
+                    const int t2 = (st + 1) / 4, n2 = (st + 1) % 4;
+                    for (int part = 0; part < 2; ++part)
+                        fb[cb ^ 1][part] = *reinterpret_cast<const bf16x8*>(b_lds + part * 2 * PL + ((n2 + t2 / 3) * 36 + t2 % 3) * 16);
+                }
+                if (tap + 1 < 9) { const int f = nt; fa[ca ^ 1][f / 2][f % 2] = *reinterpret_cast<const bf16x8*>(a_lds + (((tap + 1) * 2 + f / 2) * 2 + f % 2) * 1024); }
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][1][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // every read of the buffer has returned (the last step's operands fed its matrix instructions): free it
+            // (a counted wait on LDS only: a fence would also wait for the tile stores still in flight)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) __hip_atomic_fetch_add(cnt + 2 + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((MEM & 2) && (c & 7) == 7) {
+                const unsigned unit = (blockIdx.x * 977u + (unsigned)(c >> 3) * 4099u) % (big_units / 3);
+                float* dst = bigout + (size_t)unit * 32768 + wave * 8192;
+                for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 v = {acc[m][n][4 * q4], acc[m][n][4 * q4 + 1], acc[m][n][4 * q4 + 2], acc[m][n][4 * q4 + 3]};
+                    *reinterpret_cast<f32x4*>(dst + ((m * 4 + n) * 4 + q4) * 256 + lane * 4) = v;
+                }
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = waited; clocks[1] = clock64() - begun; }
+        float s = 0;
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 4; ++n) for (int e = 0; e < 16; ++e) s += acc[m][n][e];
+        if (s == 123.456f) out[threadIdx.x] = s;
+        return;
+    }
+    const int t = threadIdx.x - 256;
+    long long waited = 0, waited_loads = 0;
+    const long long begun = clock64();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx) + (size_t)(blockIdx.x & 255) * 131072, 0, 131072 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(src), 0, LDS, 0x00020000);
+    u32x2 rv[3][8];
+    u32x4 aw[9];
+    auto load_chunk = [&](int c) {
+        if (MEM & 1) {
+            const unsigned unit = (blockIdx.x * 131u + (unsigned)c * 7919u) % big_units;
+            const __amdgpu_buffer_rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(big) + (size_t)unit * 12288, 0, 49152, 0x00020000);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(hs, (t + i * 256) * 8 + j * 6144, 0, 0);
+        } else {
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (t + i * 256) * 8, ((c & 3) * 8 + j) * 6144, 0);
+        }
+        for (int i = 0; i < 9; ++i) aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ws, (t + i * 256) * 16, PATCH, 0);
+    };
+    // chunks 0 and 1 are in LDS already (the fill above): announce them, then stage chunks 2.. one buffer ahead
+    if (lane == 0) { __hip_atomic_fetch_add(cnt + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    load_chunk(2);
+    for (int c = 2; c < chunks; ++c) {
+        const int b = c & 1;
+        // the multiplying waves are done with this buffer's previous chunk (c - 2)
+        const long long t0 = clock64();
+        if (!wait_for(cnt + 2 + b, 4u * (unsigned)(c >> 1))) break;
+        const long long t1 = clock64();
+        __builtin_amdgcn_s_waitcnt(0x0070);                                  // every load of this chunk has landed
+        asm volatile("" ::: "memory");
+        waited += t1 - t0; waited_loads += clock64() - t1;
+        if (blockIdx.x == 0 && lane == 0 && c >= 100 && c < 104) { clocks[8 + (c - 100) * 16 + wave * 2] = t0; clocks[8 + (c - 100) * 16 + wave * 2 + 1] = t1; }
+        for (int i = 0; i < 3; ++i) {
+            if (i == 2 && t >= 136) continue;
+            for (int px = 0; px < 2; ++px) {
+                u32x4 hi, lo;
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float a = __uint_as_float(rv[i][2 * jj][px]), bb = __uint_as_float(rv[i][2 * jj + 1][px]);
+                    const unsigned h = pack_bf16(a, bb);
+                    hi[jj] = h;
+                    lo[jj] = pack_bf16(a - __uint_as_float(h << 16), bb - __uint_as_float(h & 0xffff0000u));
+                }
+                const int u = i * 256 + t, kg = u / 324, rem = u - kg * 324;
+                *reinterpret_cast<u32x4*>(lds + b * LDS + kg * PL + (rem * 2 + px) * 16) = hi;
+                *reinterpret_cast<u32x4*>(lds + b * LDS + 2 * PL + kg * PL + (rem * 2 + px) * 16) = lo;
+            }
+        }
+        for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(lds + b * LDS + PATCH + (t + i * 256) * 16) = aw[i];
+        // the LDS stores above precede the count in this wave's LDS queue; the next chunk's loads go out after it, so
+        // that nothing here waits for them
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (c + 1 < chunks) load_chunk(c + 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 256) { clocks[2] = waited; clocks[3] = waited_loads; clocks[4] = clock64() - begun; }
+    float s = __uint_as_float(rv[0][0][0]) + __uint_as_float(aw[0][0]);
+    if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+template <int MEM>
+int run_handoff(const unsigned* src, const float* gx, float* out, int chunks, const float* big, float* bigout, unsigned big_units) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1;
+    const int lds = 2 * LDS + 64;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(handoff<MEM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+    int* failed; if (hipMalloc(&failed, 1024) != hipSuccess || hipMemset(failed, 0, 1024) != hipSuccess) return 1;
+    long long* clocks = reinterpret_cast<long long*>(failed) + 1;
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        (void)hipEventRecord(e0);
+        handoff<MEM><<<256, 512, lds>>>(src, gx, out, chunks, big, bigout, big_units, failed, clocks);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    long long hc[128]; (void)hipMemcpy(hc, failed, 1024, hipMemcpyDeviceToHost); (void)hipFree(failed);
+    const int f = (int)hc[0];
+    const double flops = 2.0 * 216 * 32 * 32 * 16 * 4.0 * 256 * chunks;
+    printf("hand-over through LDS counters (8 waves, no workgroup barrier), memory bits %d: %.3f ms, %.0f TFLOP/s%s\n", MEM, best, flops / best / 1e9,
+           f ? "  ** a wait gave up: protocol failed **" : "");
+    printf("    per chunk, workgroup 0: a multiplying wave waits %.0f of %.0f clocks; a staging wave waits %.0f for its buffer and %.0f for its loads, of %.0f\n",
+           (double)hc[1] / chunks, (double)hc[2] / chunks, (double)hc[3] / chunks, (double)hc[4] / chunks, (double)hc[5] / chunks);
+    // chunks 100..103 of workgroup 0: when each wave began to wait and when its wait ended (clocks since wave 0 began to wait for chunk 100)
+    for (int c = 0; c < 4; ++c) {
+        printf("    chunk %d:", 100 + c);
+        for (int w = 0; w < 8; ++w) printf("  %s%d %lld..%lld", w < 4 ? "m" : "s", w & 3, hc[9 + c * 16 + w * 2] - hc[9], hc[9 + c * 16 + w * 2 + 1] - hc[9]);
+        printf("\n");
+    }
+    return 0;
+}
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int MODE>
@@ -397,6 +571,9 @@ int main() {
         for (int round = 0; round < 2; ++round)
             if (run_alt<3>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 128>(src, gx, out, chunks, 512, big, bigout, big_units) ||
                 run_alt<3 + 256>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 128 + 256>(src, gx, out, chunks, 512, big, bigout, big_units)) return 1;
+        for (int round = 0; round < 2; ++round)
+            if (run_handoff<0>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<1>(src, gx, out, chunks, big, bigout, big_units) ||
+                run_handoff<2>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<3>(src, gx, out, chunks, big, bigout, big_units)) return 1;
         CHECK(hipFree(big)); CHECK(hipFree(bigout));
     }
     for (int round = 0; round < 2; ++round) if (run_dual(src, gx, out, chunks, 0) || run_dual(src, gx, out, chunks, 1)) return 1;
