@@ -155,13 +155,28 @@ __global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const
                 rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(hs, (t + i * 256) * 8 + j * 6144, 0, 0);
             return;
         }
+        if (PARTS & 512) {
+            // bit 9: the same patch as 16-byte loads (four pixels of a channel per lane): 8 + 8 instructions (the
+            // second round on 104 lanes of 256) instead of 24
+            for (int j = 0; j < 8; ++j) {
+                const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 16, ((c & 3) * 8 + j) * 6144, 0);
+                rv[0][j] = u32x2{q0[0], q0[1]}; rv[1][j] = u32x2{q0[2], q0[3]};
+            }
+            if (t < 104)
+                for (int j = 0; j < 8; ++j) {
+                    const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, 4096 + t * 16, ((c & 3) * 8 + j) * 6144, 0);
+                    rv[2][j] = u32x2{q1[0] ^ q1[2], q1[1] ^ q1[3]};
+                }
+            return;
+        }
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 8; ++j)
             rv[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs, (t + i * 256) * 8, ((c & 3) * 8 + j) * 6144, 0);
     };
     auto load_aw = [&](int c) {
         for (int i = 0; i < 9; ++i) aw[i] = __builtin_amdgcn_raw_buffer_load_b128(ws, (t + i * 256) * 16, PATCH, 0);
     };
-    load_raw(0); load_aw(0);
+    load_raw(0);
+    if (!(PARTS & 1024)) load_aw(0); else for (int i = 0; i < 9; ++i) aw[i] = u32x4{0u, 0u, 0u, 0u};
     for (int c = 0; c < chunks; ++c) {
         if ((PARTS & 256) && (c & 7) == 7) {
             // bit 8: every 8 chunks the tile leaves: 128 KiB per workgroup, 16-byte stores, to memory of its own
@@ -171,6 +186,13 @@ __global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const
                 const f32x4 v = {acc[m][n][4 * q4], acc[m][n][4 * q4 + 1], acc[m][n][4 * q4 + 2], acc[m][n][4 * q4 + 3]};
                 *reinterpret_cast<f32x4*>(dst + ((m * 4 + n) * 4 + q4) * 1024 + t * 4) = v;
             }
+        }
+        if (PARTS & 1024) {
+            // bit 10: the chunk's weights go from global memory straight into LDS (16 bytes per lane, a wave's 1 KiB
+            // contiguous), requested once every wave is done with the previous chunk's, landed under the conversions
+            for (int i = 0; i < 9; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (__attribute__((address_space(3))) void*)(lds + PATCH + (i * 256 + wave * 64) * 16), 16,
+                                                         (t + i * 256) * 16, PATCH, 0, 0);
         }
         if (PARTS & 1) {
             for (int i = 0; i < 3; ++i) {
@@ -190,8 +212,9 @@ __global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const
                     *reinterpret_cast<u32x4*>(lds + 2 * PL + kg * PL + (rem * 2 + px) * 16) = lo;
                 }
             }
-            if (!(PARTS & 8)) for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(lds + PATCH + (t + i * 256) * 16) = aw[i];
+            if (!(PARTS & (8 | 1024))) for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(lds + PATCH + (t + i * 256) * 16) = aw[i];
         }
+        if (PARTS & 1024) __builtin_amdgcn_s_waitcnt(0x0070);
         __syncthreads();
         if ((PARTS & 1) && !(PARTS & (32 | 64))) load_raw(c + 1);
         if (PARTS & 2) {
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void alternating(const unsigned* src, const
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if ((PARTS & 1) && !(PARTS & (40 | 64))) load_aw(c + 1);
+        if ((PARTS & 1) && !(PARTS & (40 | 64 | 1024))) load_aw(c + 1);
         __syncthreads();
     }
     float s = 0;
@@ -439,6 +462,7 @@ __global__ __launch_bounds__(512, 1) void handoff(const unsigned* src, const flo
     const int t = threadIdx.x - 256;
     long long waited = 0, waited_loads = 0;
     const long long begun = clock64();
+    if (MEM & 4) __builtin_amdgcn_s_setprio(3);      // bit 2: the staging waves ask for the issue slots first
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx) + (size_t)(blockIdx.x & 255) * 131072, 0, 131072 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(src), 0, LDS, 0x00020000);
     u32x2 rv[3][8];
@@ -571,9 +595,13 @@ int main() {
         for (int round = 0; round < 2; ++round)
             if (run_alt<3>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 128>(src, gx, out, chunks, 512, big, bigout, big_units) ||
                 run_alt<3 + 256>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 128 + 256>(src, gx, out, chunks, 512, big, bigout, big_units)) return 1;
+        for (int round = 0; round < 3; ++round)
+            if (run_alt<3>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 1024>(src, gx, out, chunks, 512, big, bigout, big_units) || run_alt<3 + 8>(src, gx, out, chunks, 512, big, bigout, big_units) ||
+                run_alt<3 + 32>(src, gx, out, chunks, 512, big, bigout, big_units)) return 1;
         for (int round = 0; round < 2; ++round)
             if (run_handoff<0>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<1>(src, gx, out, chunks, big, bigout, big_units) ||
-                run_handoff<2>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<3>(src, gx, out, chunks, big, bigout, big_units)) return 1;
+                run_handoff<2>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<3>(src, gx, out, chunks, big, bigout, big_units) ||
+                run_handoff<4>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<7>(src, gx, out, chunks, big, bigout, big_units)) return 1;
         CHECK(hipFree(big)); CHECK(hipFree(bigout));
     }
     for (int round = 0; round < 2; ++round) if (run_dual(src, gx, out, chunks, 0) || run_dual(src, gx, out, chunks, 1)) return 1;
