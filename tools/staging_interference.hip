@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void handoff(const unsigned* src, const flo
             ok = wait_for(cnt + b, 4u * ((unsigned)(c >> 1) + 1u));
             const long long t1m = clock64();
             waited += t1m - t0;
-            if (blockIdx.x == 0 && threadIdx.x < 256 && lane == 0 && c >= 100 && c < 104) { clocks[8 + (c - 100) * 16 + wave * 2] = t0; clocks[8 + (c - 100) * 16 + wave * 2 + 1] = t1m; }
+            if (blockIdx.x == 0 && threadIdx.x < 256 && lane == 0 && c >= 100 && c < 104) { clocks[16 + (c - 100) * 16 + wave * 2] = t0; clocks[16 + (c - 100) * 16 + wave * 2 + 1] = t1m; }
             const unsigned char* a_lds = a_lds0 + b * LDS;
             const unsigned char* b_lds = b_lds0 + b * LDS;
             bf16x8 fa[2][2][2], fb[2][2];
@@ -431,6 +431,14 @@ __global__ __launch_bounds__(512, 1) void handoff(const unsigned* src, const flo
                 }
                 if (tap + 1 < 9) { const int f = nt; fa[ca ^ 1][f / 2][f % 2] = *reinterpret_cast<const bf16x8*>(a_lds + (((tap + 1) * 2 + f / 2) * 2 + f % 2) * 1024); }
                 for (int mt = 0; mt < 2; ++mt) {
+                    if (MEM & 8) {
+                        // bit 3: the accumulators live in the accumulation registers (the compiler keeps them in
+                        // ordinary vector registers when the budget allows)
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(fa[ca][1][mt]), "v"(fb[cb][0]));
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(fa[ca][0][mt]), "v"(fb[cb][1]));
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(fa[ca][0][mt]), "v"(fb[cb][0]));
+                        continue;
+                    }
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][1][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][1], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ca][0][mt], fb[cb][0], acc[mt][nt], 0, 0, 0);
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void handoff(const unsigned* src, const flo
         return;
     }
     const int t = threadIdx.x - 256;
-    long long waited = 0, waited_loads = 0;
+    long long waited = 0, waited_loads = 0, spent_patch = 0, spent_weights = 0, spent_requests = 0;
     const long long begun = clock64();
     if (MEM & 4) __builtin_amdgcn_s_setprio(3);      // bit 2: the staging waves ask for the issue slots first
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx) + (size_t)(blockIdx.x & 255) * 131072, 0, 131072 * 4, 0x00020000);
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(512, 1) void handoff(const unsigned* src, const flo
         __builtin_amdgcn_s_waitcnt(0x0070);                                  // every load of this chunk has landed
         asm volatile("" ::: "memory");
         waited += t1 - t0; waited_loads += clock64() - t1;
-        if (blockIdx.x == 0 && lane == 0 && c >= 100 && c < 104) { clocks[8 + (c - 100) * 16 + wave * 2] = t0; clocks[8 + (c - 100) * 16 + wave * 2 + 1] = t1; }
+        if (blockIdx.x == 0 && lane == 0 && c >= 100 && c < 104) { clocks[16 + (c - 100) * 16 + wave * 2] = t0; clocks[16 + (c - 100) * 16 + wave * 2 + 1] = t1; }
         for (int i = 0; i < 3; ++i) {
             if (i == 2 && t >= 136) continue;
             for (int px = 0; px < 2; ++px) {
@@ -505,15 +513,22 @@ __global__ __launch_bounds__(512, 1) void handoff(const unsigned* src, const flo
                 *reinterpret_cast<u32x4*>(lds + b * LDS + 2 * PL + kg * PL + (rem * 2 + px) * 16) = lo;
             }
         }
+        const long long t2 = clock64();
         for (int i = 0; i < 9; ++i) *reinterpret_cast<u32x4*>(lds + b * LDS + PATCH + (t + i * 256) * 16) = aw[i];
         // the LDS stores above precede the count in this wave's LDS queue; the next chunk's loads go out after it, so
         // that nothing here waits for them
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
+        const long long t3 = clock64();
         if (c + 1 < chunks) load_chunk(c + 1);
+        const long long t4 = clock64();
+        spent_patch += t2 - t1; spent_weights += t3 - t2; spent_requests += t4 - t3;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 256) { clocks[2] = waited; clocks[3] = waited_loads; clocks[4] = clock64() - begun; }
+    if (blockIdx.x == 0 && threadIdx.x == 256) {
+        clocks[2] = waited; clocks[3] = waited_loads; clocks[4] = clock64() - begun;
+        clocks[5] = spent_patch; clocks[6] = spent_weights; clocks[7] = spent_requests;
+    }
     float s = __uint_as_float(rv[0][0][0]) + __uint_as_float(aw[0][0]);
     if (s == 123.456f) out[threadIdx.x] = s;
 }
@@ -540,10 +555,12 @@ int run_handoff(const unsigned* src, const float* gx, float* out, int chunks, co
            f ? "  ** a wait gave up: protocol failed **" : "");
     printf("    per chunk, workgroup 0: a multiplying wave waits %.0f of %.0f clocks; a staging wave waits %.0f for its buffer and %.0f for its loads, of %.0f\n",
            (double)hc[1] / chunks, (double)hc[2] / chunks, (double)hc[3] / chunks, (double)hc[4] / chunks, (double)hc[5] / chunks);
+    printf("    the staging wave's clocks per chunk: %.0f waiting for loads + converting and storing the patch, %.0f storing the weights and signalling, %.0f requesting the next chunk\n",
+           (double)hc[6] / chunks, (double)hc[7] / chunks, (double)hc[8] / chunks);
     // chunks 100..103 of workgroup 0: when each wave began to wait and when its wait ended (clocks since wave 0 began to wait for chunk 100)
     for (int c = 0; c < 4; ++c) {
         printf("    chunk %d:", 100 + c);
-        for (int w = 0; w < 8; ++w) printf("  %s%d %lld..%lld", w < 4 ? "m" : "s", w & 3, hc[9 + c * 16 + w * 2] - hc[9], hc[9 + c * 16 + w * 2 + 1] - hc[9]);
+        for (int w = 0; w < 8; ++w) printf("  %s%d %lld..%lld", w < 4 ? "m" : "s", w & 3, hc[17 + c * 16 + w * 2] - hc[17], hc[17 + c * 16 + w * 2 + 1] - hc[17]);
         printf("\n");
     }
     return 0;
@@ -601,7 +618,7 @@ int main() {
         for (int round = 0; round < 2; ++round)
             if (run_handoff<0>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<1>(src, gx, out, chunks, big, bigout, big_units) ||
                 run_handoff<2>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<3>(src, gx, out, chunks, big, bigout, big_units) ||
-                run_handoff<4>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<7>(src, gx, out, chunks, big, bigout, big_units)) return 1;
+                run_handoff<8>(src, gx, out, chunks, big, bigout, big_units) || run_handoff<11>(src, gx, out, chunks, big, bigout, big_units)) return 1;
         CHECK(hipFree(big)); CHECK(hipFree(bigout));
     }
     for (int round = 0; round < 2; ++round) if (run_dual(src, gx, out, chunks, 0) || run_dual(src, gx, out, chunks, 1)) return 1;
