@@ -228,18 +228,25 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                     v[j][1] = ok ? fmaxf(fmaf(v[j][1], ss.x, ss.y), 0.0f) : 0.0f;
                 }
             }
+            // the remainders are taken on the register pairs the loads delivered (a channel's two pixels): two-wide
+            // subtractions with no register moves to pair their operands up
+            u32x4 hi[2], lo[2];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x2 a = {v[2 * jj][0], v[2 * jj][1]}, b = {v[2 * jj + 1][0], v[2 * jj + 1][1]};
+                const unsigned h0 = pack_bf16(a[0], b[0]), h1 = pack_bf16(a[1], b[1]);
+                const f32x2 ha = {__uint_as_float(h0 << 16), __uint_as_float(h1 << 16)};
+                const f32x2 hb = {__uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 & 0xffff0000u)};
+                const f32x2 la = a - ha, lb = b - hb;
+                hi[0][jj] = h0;
+                hi[1][jj] = h1;
+                lo[0][jj] = pack_bf16(la[0], lb[0]);
+                lo[1][jj] = pack_bf16(la[1], lb[1]);
+            }
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                u32x4 hi, lo;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const float a = v[2 * jj][px], b = v[2 * jj + 1][px];
-                    const unsigned h = pack_bf16(a, b);
-                    hi[jj] = h;
-                    lo[jj] = pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
-                }
-                *reinterpret_cast<u32x4*>(lds + u_lds[i] + px * PX_STEP) = hi;
-                *reinterpret_cast<u32x4*>(lds + 2 * PLANE + u_lds[i] + px * PX_STEP) = lo;
+                *reinterpret_cast<u32x4*>(lds + u_lds[i] + px * PX_STEP) = hi[px];
+                *reinterpret_cast<u32x4*>(lds + 2 * PLANE + u_lds[i] + px * PX_STEP) = lo[px];
             }
         }
     };
