@@ -115,6 +115,12 @@ int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_stride, int 
  * (pool2x) of the same multi-level GRU (core/update.py of the RAFT-Stereo model built at
  * stereo/stereo_disparity_RAFT.py:46).  Both tensors dense. */
 int vo_avg_pool3x3s2(const void* in, void* out, int64_t planes, int h, int w, int dtype, void* stream);
+/* The same pooling of (batch,channels,h,w) written into a channel slice of a wider tensor: items of out are
+ * out_batch_stride ELEMENTS apart (0 = dense), each a dense (channels,H,W) block.  The multi-level GRU of
+ * RAFT-Stereo (core/update.py of the model built at stereo/stereo_disparity_RAFT.py:46) concatenates the pooled
+ * state of the finer level behind its own hidden state; this writes it where the concatenation would put it. */
+int vo_avg_pool3x3s2_into(const void* in, void* out, int64_t out_batch_stride, int batch, int channels, int h, int w,
+                          int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
  * 3x3, stride 1, padding 1 float32 convolution (NCHW, no bias) as Winograd F(2x2,3x3)

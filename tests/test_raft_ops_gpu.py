@@ -817,6 +817,20 @@ def test_kernels_write_channel_slices_in_place(vo, tile):
         ops.resize_bilinear(small, (H, W), out=wide[:, 2:7])
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(x, ops.winograd_filter(w, tile), K, out=wide.permute(0, 1, 3, 2)[:, :K])
+    # the 3x3 stride-2 average into a slice (vo_avg_pool3x3s2_into): float32 and float16, rows of 12 (16-byte stores)
+    # and of 7 pixels (element stores), bit for bit what the dense call returns
+    for (h, w) in ((18, 24), (9, 13)):
+        for dt in (torch.float32, torch.float16):
+            big = _rand(N, 5, h, w, seed=104).to(DEV).to(dt)
+            dense = ops.avg_pool3x3s2(big)
+            wide = torch.full((N, 9, (h - 1) // 2 + 1, (w - 1) // 2 + 1), 0.75, device=DEV, dtype=dt)
+            got = ops.avg_pool3x3s2(big, out=wide[:, 3:8])
+            assert got.data_ptr() == wide[:, 3:8].data_ptr() and torch.equal(wide[:, 3:8], dense)
+            assert torch.all(wide[:, :3] == 0.75) and torch.all(wide[:, 8:] == 0.75)
+            want = Fn.avg_pool2d(big.double(), 3, stride=2, padding=1)
+            assert (dense.double() - want).abs().max().item() < (1e-6 if dt == torch.float32 else 2e-3)
+    with pytest.raises(ValueError):
+        ops.avg_pool3x3s2(big, out=wide[:, 3:7])
 
 
 SPLIT_TOL = 2e-5                   # relative to the largest output value (measured 4-6e-6)

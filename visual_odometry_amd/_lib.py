@@ -27,6 +27,7 @@ SIGNATURES = {
     "vo_add_relu": [_P, _P, _L, _I, _P],
     "vo_resize_bilinear": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_avg_pool3x3s2": [_P, _P, _L, _I, _I, _I, _P],
+    "vo_avg_pool3x3s2_into": [_P, _P, _L, _I, _I, _I, _I, _I, _P],
     "vo_winograd_filter": [_P, _P, _I, _I, _P],
     "vo_conv3x3_winograd": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     "vo_winograd4_filter": [_P, _P, _I, _I, _P],

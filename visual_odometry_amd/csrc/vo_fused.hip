@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void resize_window_kernel(const T* __restrict_
 // One lane per 4 output pixels of a row: 9 input columns of 3 rows.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t total, int h, int w,
-                                                   int H, int W, bool vec) {
+                                                   int H, int W, bool vec, int64_t channels, int64_t out_batch_stride) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int wq = (W + 3) >> 2;
@@ -290,7 +290,9 @@ __global__ __launch_bounds__(256) void pool_kernel(const T* __restrict__ in, T* 
                 if (xb + j < w) col[1 + j] += vo_ld1(r, xb + j);
         }
     }
-    T* o = out + (plane * H + y) * (int64_t)W + 4 * xq;
+    // the output may be a channel slice of a wider tensor: items out_batch_stride elements apart
+    const int64_t item = plane / channels;
+    T* o = out + item * out_batch_stride + ((plane - item * channels) * H + y) * (int64_t)W + 4 * xq;
     const float k = 1.0f / 9.0f;
     float v[4];
 #pragma unroll
@@ -350,23 +352,41 @@ extern "C" int vo_resize_bilinear(const void* in, void* out, int64_t out_batch_s
     return VO_OK;
 }
 
-extern "C" int vo_avg_pool3x3s2(const void* in, void* out, int64_t planes, int h, int w, int dtype, void* stream) {
-    VO_REQUIRE(in && out, "vo_avg_pool3x3s2: null pointer");
-    VO_REQUIRE(planes > 0 && h > 0 && w > 0, "vo_avg_pool3x3s2: bad sizes");
-    if (int rc = check_dtype("vo_avg_pool3x3s2", dtype)) return rc;
+namespace {
+int launch_pool(const char* name, const void* in, void* out, int64_t out_batch_stride, int64_t batch, int64_t channels, int h, int w,
+                int dtype, void* stream) {
+    if (!in || !out) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
+    if (batch <= 0 || channels <= 0 || h <= 0 || w <= 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes", name);
+    if (int rc = check_dtype(name, dtype)) return rc;
     const int H = (h - 1) / 2 + 1, W = (w - 1) / 2 + 1;
-    const int64_t total = planes * H * ((W + 3) / 4);
+    if (out_batch_stride == 0) out_batch_stride = channels * H * W;
+    if (out_batch_stride < channels * H * W) return vo_fail(VO_ERR_INVALID_ARG, "%s: out_batch_stride smaller than one item", name);
+    const int64_t total = batch * channels * H * ((W + 3) / 4);
     const int64_t blocks = vo_ceil_div(total, 256);
-    if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_avg_pool3x3s2: grid too large");
+    if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "%s: grid too large", name);
     const size_t es = dtype == VO_F16 ? 2 : 4;
-    const bool vec = (w & 3) == 0 && vo_vec4_ok(in, es) && vo_vec4_ok(out, es);     // rows of both tensors 4-element aligned
+    // rows of both tensors 4-element aligned
+    const bool vec = (w & 3) == 0 && (out_batch_stride & 3) == 0 && vo_vec4_ok(in, es) && vo_vec4_ok(out, es);
     const dim3 grid((unsigned)blocks);
     if (dtype == VO_F16)
-        pool_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((const __half*)in, (__half*)out, total, h, w, H, W, vec);
+        pool_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((const __half*)in, (__half*)out, total, h, w, H, W, vec, channels,
+                                                                      out_batch_stride);
     else
-        pool_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((const float*)in, (float*)out, total, h, w, H, W, vec);
-    VO_CHECK_LAUNCH("vo_avg_pool3x3s2");
+        pool_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((const float*)in, (float*)out, total, h, w, H, W, vec, channels,
+                                                                     out_batch_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;
+}
+}  // namespace
+
+extern "C" int vo_avg_pool3x3s2(const void* in, void* out, int64_t planes, int h, int w, int dtype, void* stream) {
+    return launch_pool("vo_avg_pool3x3s2", in, out, 0, 1, planes, h, w, dtype, stream);
+}
+
+extern "C" int vo_avg_pool3x3s2_into(const void* in, void* out, int64_t out_batch_stride, int batch, int channels, int h, int w,
+                                     int dtype, void* stream) {
+    return launch_pool("vo_avg_pool3x3s2_into", in, out, out_batch_stride, batch, channels, h, w, dtype, stream);
 }
 
 extern "C" int vo_instance_norm_relu(void* x, const void* skip, int64_t planes, int64_t hw, float eps, int relu,

@@ -210,12 +210,20 @@ def resize_bilinear(x: torch.Tensor, size, out: torch.Tensor | None = None) -> t
     return out
 
 
-def avg_pool3x3s2(x: torch.Tensor) -> torch.Tensor:
-    """(B,C,h,w) -> (B,C,(h-1)//2+1,(w-1)//2+1): avg_pool2d(x, 3, stride=2, padding=1)."""
+def avg_pool3x3s2(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """(B,C,h,w) -> (B,C,(h-1)//2+1,(w-1)//2+1): avg_pool2d(x, 3, stride=2, padding=1).  ``out`` may be a channel
+    slice of a wider NCHW tensor (dense (C,H,W) blocks, any batch stride)."""
     B, C, h, w = x.shape
+    H, W = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     px, dt, es = _act(x, "x")
-    out = torch.empty((B, C, (h - 1) // 2 + 1, (w - 1) // 2 + 1), device=x.device, dtype=x.dtype)
-    _call("vo_avg_pool3x3s2", px, out.data_ptr(), B * C, h, w, dt, _stream(), nbytes=es * (x.numel() + out.numel()))
+    if out is None:
+        out = torch.empty((B, C, H, W), device=x.device, dtype=x.dtype)
+        _call("vo_avg_pool3x3s2", px, out.data_ptr(), B * C, h, w, dt, _stream(), nbytes=es * (x.numel() + out.numel()))
+        return out
+    if tuple(out.shape) != (B, C, H, W):
+        raise ValueError("out must be (B,C,H,W)")
+    po, so = _slice(out, "out", x)
+    _call("vo_avg_pool3x3s2_into", px, po, so, B, C, h, w, dt, _stream(), nbytes=es * (x.numel() + out.numel()))
     return out
 
 

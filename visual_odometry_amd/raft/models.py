@@ -221,10 +221,10 @@ class RAFTStereo(nn.Module):
             with fused_passes():
                 if c.n_gru_layers == 3 and c.slow_fast_gru:
                     net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False,
-                                                 update=False)
+                                                 update=False, state=state)
                 if c.n_gru_layers >= 2 and c.slow_fast_gru:
                     net_list = self.update_block(net_list, inp_list, iter32=c.n_gru_layers == 3, iter16=True,
-                                                 iter08=False, update=False)
+                                                 iter08=False, update=False, state=state)
                 net_list, raw_mask, delta = self.update_block(net_list, inp_list, window.to(act), flow.to(act),
                                                               iter32=c.n_gru_layers == 3, iter16=c.n_gru_layers >= 2,
                                                               want_mask=(it == iters - 1), state=state)

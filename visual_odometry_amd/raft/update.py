@@ -313,9 +313,35 @@ class BasicMultiUpdateBlock(nn.Module):
 
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
                 want_mask: bool = True, state=None):
-        if iter32:
+        # fused path: every level keeps a persistent input buffer [h | the other levels' state] across the
+        # iterations of one forward pass; the pooled / interpolated states are written into their channel
+        # slices, h is left in the first channels by the GRU of the previous call
+        buffers = fused_on() and state is not None and net[0].is_cuda and net[0].dtype in (torch.float32, torch.float16)
+
+        def level_buffer(key, h, extra):
+            buf = state.get(key)
+            if buf is None:
+                B, C, H, W = h.shape
+                buf = torch.empty((B, C + extra, H, W), device=h.device, dtype=h.dtype)
+                buf[:, :C].copy_(h)
+                state[key] = buf
+            return buf
+
+        if iter32 and buffers:
+            C = net[2].shape[1]
+            buf = level_buffer("buf32", net[2], net[1].shape[1])
+            ops.avg_pool3x3s2(net[1].contiguous(), out=buf[:, C:])
+            net[2] = self.gru32(net[2], *(inp[2]), buf=buf)
+        elif iter32:
             net[2] = self.gru32(net[2], *(inp[2]), pool2x(net[1]))
-        if iter16:
+        if iter16 and buffers:
+            C, C0 = net[1].shape[1], net[0].shape[1]
+            buf = level_buffer("buf16", net[1], C0 + (net[2].shape[1] if self.n_gru_layers > 2 else 0))
+            ops.avg_pool3x3s2(net[0].contiguous(), out=buf[:, C:C + C0])
+            if self.n_gru_layers > 2:
+                ops.resize_bilinear(net[2].contiguous(), net[1].shape[2:], out=buf[:, C + C0:])
+            net[1] = self.gru16(net[1], *(inp[1]), buf=buf)
+        elif iter16:
             if self.n_gru_layers > 2:
                 net[1] = self.gru16(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
             else:
