@@ -139,6 +139,42 @@ def test_corr_volume_presplit_exact_on_integers_and_1d(vo):
         ops.split_feature_rows(torch.zeros(4, 48, device=DEV), 32)              # D not a multiple of the block
 
 
+def test_correlation_chain_properties_at_full_size(vo):
+    """The 640x480 geometry (60x80 maps of 256 features, 16 pairs, 1.5 GB of volume), where no CPU restatement
+    finishes in seconds: properties that need none.  Scaling a map by a power of two scales the volume exactly
+    (bit for bit, both kernels); swapping the maps transposes it (to the rounding of the two small terms, which
+    swap their order); every pyramid level has the mean of the one below where its size is even; a lookup at
+    integer coordinates returns volume entries as they are, zeros outside."""
+    from visual_odometry_amd import ops
+    B, H, W, D = 16, 60, 80, 256
+    N = H * W
+    f1, f2 = _rand(B, H, W, D, seed=301).to(DEV), _rand(B, H, W, D, seed=302).to(DEV)
+    s1, s2 = ops.split_feature_rows(f1, 32), ops.split_feature_rows(f2, 32)
+    vol = ops.corr_volume_2d_presplit(s1, s2)
+    assert torch.equal(vol, ops.corr_volume_2d(f1, f2, split=True))
+    assert torch.equal(ops.corr_volume_2d_presplit(ops.split_feature_rows(f1 * 4.0, 32), s2), vol * 4.0)
+    swapped = ops.corr_volume_2d_presplit(s2, s1).view(B, N, N).transpose(1, 2)
+    top = vol.abs().max().item()
+    assert (swapped - vol.view(B, N, N)).abs().max().item() < 2e-6 * top
+    del swapped
+    pyr = ops.corr_pyramid_2d(vol, 4)
+    assert [tuple(p.shape[2:]) for p in pyr] == [(60, 80), (30, 40), (15, 20), (7, 10)]
+    m = [p.double().mean(dim=(2, 3)) for p in pyr[:3]]
+    assert (m[1] - m[0]).abs().max().item() < 1e-6 * top and (m[2] - m[1]).abs().max().item() < 1e-6 * top
+    # level 3 drops the odd last row of level 2: its mean is the mean of the 14 rows it covers
+    m2 = pyr[2][:, :, :14].double().mean(dim=(2, 3))
+    assert (pyr[3].double().mean(dim=(2, 3)) - m2).abs().max().item() < 1e-6 * top
+    coords = raft_ref.coords_grid(B, H, W).to(DEV)
+    win = ops.corr_lookup_2d(pyr[:1], coords, 4)                      # (B, 81, H, W): channel = x-offset index * 9 + y-offset index
+    v5 = vol.view(B, H, W, H, W)
+    ys, xs = torch.meshgrid(torch.arange(H, device=DEV), torch.arange(W, device=DEV), indexing="ij")
+    for (dx, dy) in ((0, 0), (-4, -4), (4, 4), (3, -2), (-1, 4)):
+        ty, tx = ys + dy, xs + dx
+        ok = (ty >= 0) & (ty < H) & (tx >= 0) & (tx < W)
+        want = torch.where(ok[None], v5[:, ys, xs, ty.clamp(0, H - 1), tx.clamp(0, W - 1)], torch.zeros((), device=DEV))
+        assert torch.equal(win[:, (dx + 4) * 9 + (dy + 4)], want)
+
+
 def test_corr_rejects_bad_input(vo):
     from visual_odometry_amd import ops
     from visual_odometry_amd._lib import VoHipError
