@@ -1165,6 +1165,47 @@ def test_split_bf16_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
         assert (got2 - want2).abs().max().item() < 1e-4 * max(1.0, want2.abs().max().item())
 
 
+def test_streaming_conv1x1_equals_the_template_kernel_bit_for_bit(vo):
+    """Layers with whole blocks of 64 output channels and planes of whole groups of four pixels run on the kernel that
+    keeps the weights in LDS; VO_HIP_CONV1X1_TEMPLATE=1 keeps them on the convolution template.  Same weights image,
+    same order of terms: the results are the same bits -- checked over repeated runs (the two waves a SIMD holds
+    run independently of each other), many channel counts (few and many chunks, odd and even), planes smaller than
+    a wave's share and larger than a tile, the motion encoder's full shape, scale + bias + ReLU, a channel slice."""
+    import os, random
+    from visual_odometry_amd import ops
+    rnd = random.Random(5)
+    shapes = [(2, 64, 60, 80, 64), (1, 128, 120, 160, 256), (2, 112, 120, 160, 256), (3, 336, 60, 80, 256), (2, 256, 60, 80, 576),
+              (2, 64, 8, 6, 128), (24, 336, 60, 80, 256), (5, 576, 30, 40, 64), (7, 608, 15, 20, 192), (3, 80, 33, 44, 320)]
+    shapes += [(rnd.randint(1, 5), 16 * rnd.randint(4, 38), rnd.randint(1, 70), 4 * rnd.randint(1, 40), 64 * rnd.randint(1, 9)) for _ in range(14)]
+
+    def template(fn):
+        os.environ["VO_HIP_CONV1X1_TEMPLATE"] = "1"
+        try:
+            return fn()
+        finally:
+            del os.environ["VO_HIP_CONV1X1_TEMPLATE"]
+
+    for (N, C, H, W, K) in shapes:
+        x = _rand(N, C, H, W, seed=400 + C).to(DEV)
+        w = (_rand(K, C, 1, 1, seed=401) / C ** 0.5).to(DEV)
+        b, sc = _rand(K, seed=402).to(DEV), (_rand(K, seed=403).abs() + 0.5).to(DEV)
+        A = ops.conv1x1_split_filter(w)
+        rec = {}
+        ops.set_recorder(rec)
+        got = ops.conv1x1_split(x, A, K)
+        ops.set_recorder(None)
+        assert "vo_conv1x1_bf16x3" in rec
+        want, want2 = template(lambda: ops.conv1x1_split(x, A, K)), template(lambda: ops.conv1x1_split(x, A, K, sc, b, True))
+        for _ in range(3):
+            assert torch.equal(ops.conv1x1_split(x, A, K), want), (N, C, H, W, K)
+            assert torch.equal(ops.conv1x1_split(x, A, K, sc, b, True), want2), (N, C, H, W, K)
+        assert torch.equal(got, want)
+        wide = torch.full((N, K + 8, H, W), 2.5, device=DEV)
+        ops.conv1x1_split(x, A, K, None, b, False, out=wide[:, 4:4 + K])
+        assert torch.equal(wide[:, 4:4 + K], template(lambda: ops.conv1x1_split(x, A, K, None, b, False)))
+        assert torch.all(wide[:, :4] == 2.5) and torch.all(wide[:, 4 + K:] == 2.5)
+
+
 def test_instance_norm_join_normalises_a_raw_skip_branch(vo):
     """vo_instance_norm_apply with skip statistics: relu(act(norm(skip)) + relu(norm(x))) from two raw tensors
     and their plane sums, against the stock operators, with and without the ReLU on the skip branch."""

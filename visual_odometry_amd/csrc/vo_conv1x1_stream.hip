@@ -1,26 +1,20 @@
-// EXPERIMENT, NOT BUILT (kept as text): a weights-stationary streaming kernel for the many-channel 1x1 layers.
-// Measured at 192 pairs (MI355X): 336 -> 256 @60x80 0.69 ms with 8 waves per workgroup, 0.76 ms with 4, against
-// 1.16 ms of the shipped kernel (vo_conv_bf16x3.hip, one tap per chunk); 256 -> 576: 1.29 / 1.54 against 2.01 ms.
-// NOT ADOPTED: with 8 waves per workgroup (two waves per SIMD, 230-256 vector registers) the results of layers with
-// at most 128 input channels were sporadically wrong -- always accumulator registers 0 and 1 of the first tile, lanes
-// 12-15 of every row of 16, in waves 4-7, different from run to run; layers with 144 and more input channels passed
-// every run.  Ruled out by experiment: loads behind branches, loads past the image, register spills, idle cycles
-// between the last matrix instruction and the store, draining every memory operation between tiles.  The variant
-// with 4 waves (accumulators in the accumulation registers, one wave per SIMD) passed every run, but the cause of
-// the 8-wave failure was not found, so neither is shipped.
 // 1x1 stride-1 convolution with many channels on both sides, float32 in and out (NCHW), every product from three
-// bf16 matrix-core terms (see vo_conv_bf16x3.hip for the arithmetic; same weights image, same order of terms):
-// the motion encoder's first layer (correlation window -> 256 channels, every refinement iteration) and the mask
-// heads' last layer.
+// bf16 matrix-core terms (see vo_conv_bf16x3.hip for the arithmetic; same weights image, same order of terms, the
+// same bits in the result): the motion encoder's first layer (correlation window -> 256 channels, every refinement
+// iteration) and the mask head's last layer.
 //
 // A 1x1 layer has one tap: 24 matrix instructions per chunk of 16 input channels and wave, against 216 for a 3x3
 // layer, so a kernel that stages patch and weights through LDS chunk by chunk spends its time at the two barriers
 // of a chunk.  Here the WEIGHTS stay: a workgroup of 8 waves copies the whole image of its 64 output channels
 // (C x 256 bytes: 84 KiB for 336 input channels) into LDS once and then walks over pixel tiles with no barrier at
-// all; every wave owns 128 pixels of a tile, loads its own input (already the B operand's shape: a lane takes
-// eight channels of NTL consecutive pixels, 16 bytes per channel), splits it in registers, and keeps the next
-// chunk's loads in flight while it multiplies.  One workgroup per CU; the workgroups of the channel blocks of one
-// layer walk the same pixel tiles at the same time and sit on the same XCD, so the input is read from memory once.
+// all; every wave owns 64 pixels of a tile, loads its own input (already the B operand's shape: a lane takes
+// eight channels of NTL consecutive pixels), splits it in registers, and keeps the next chunk's loads in flight
+// while it multiplies.  The workgroups of the channel blocks of one layer walk the same pixel tiles at the same
+// time and sit on the same XCD, so the input is read from memory once.
+// (A variant with 128 pixels per wave, 230-256 vector registers, was faster still on the widest layer but returned
+// sporadically wrong accumulator values with 8 waves per workgroup; the cause was not found.  This form, 134
+// registers, equals the template's kernel bit for bit on every shape tried; tests/test_raft_ops_gpu.py keeps
+// comparing the two.)
 #include "vo_common.h"
 
 namespace {
@@ -30,13 +24,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CK = 16;                        // input channels per chunk (the k of one matrix instruction)
 constexpr int KB = 64;                        // output channels per workgroup
 constexpr int A_CHUNK = 2 * 2 * 64 * 16;      // bytes of weights per chunk: [part][m-tile][lane][16]
-constexpr int NTL = 4;                        // pixel tiles of 32 pixels per wave
+constexpr int NTL = 2;                        // pixel tiles of 32 pixels per wave (a lane's NTL pixels are consecutive)
 constexpr int PW = 32 * NTL;                  // pixels per wave
-constexpr int WAVES = 4;
+constexpr int WAVES = 8;
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -45,7 +40,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 struct StreamEp { const float* scale; const float* shift; int relu; int64_t y_batch_stride; };
 
-__global__ __launch_bounds__(64 * WAVES, 1) void conv1x1_stream_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
+__global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
                                                                      float* __restrict__ y, StreamEp ep, int C, int P, int K,
                                                                      int kblocks, int ptiles, int items, int groups) {
     extern __shared__ __align__(16) unsigned char lds[];         // the channel block's weights: nchunks x A_CHUNK
@@ -82,13 +77,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv1x1_stream_kernel(const flo
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][t][e] = 0.0f;
 
-        u32x4 b0[8], b1[8];
-        auto load = [&](u32x4 (&b)[8], int chunk) {
+        u32x2 b0[8], b1[8];
+        auto load = [&](u32x2 (&b)[8], int chunk) {
             chunk = chunk < nchunks ? chunk : nchunks - 1;       // past the end: reloaded, never used
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, x_off, (chunk * CK + j) * P * 4, 0);
+            for (int j = 0; j < 8; ++j) b[j] = __builtin_amdgcn_raw_buffer_load_b64(xrs, x_off, (chunk * CK + j) * P * 4, 0);
         };
-        auto multiply = [&](const u32x4 (&b)[8], int chunk) {
+        auto multiply = [&](const u32x2 (&b)[8], int chunk) {
             const unsigned char* a = a_lds + chunk * A_CHUNK;
             bf16x8 fa[2][2];
 #pragma unroll
@@ -149,14 +144,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv1x1_stream_kernel(const flo
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ku = kb * KB + mt * 32 + (e & 3) + 8 * (e >> 2);
-                u32x4 o;
+                u32x2 o;
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) {
                     float v = ep.shift ? fmaf(acc[mt][t][e], scv[e], shv[e]) : acc[mt][t][e];
                     if (ep.relu) v = fmaxf(v, 0.0f);
                     o[t] = __float_as_uint(v);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, yrs, y_off, ku * P * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(o, yrs, y_off, ku * P * 4, 0);
             }
         }
     }
@@ -190,8 +185,13 @@ int vo_conv1x1_stream_launch(const char* name, const float* x, const void* arran
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
         cus = 256;
-    // one workgroup per CU; per XCD a whole number of groups of kblocks workgroups, no more groups than items
-    int per_xcd = cus / 8 / kblocks;
+    // as many workgroups per CU as their weights leave room for in LDS (at most 3); per XCD a whole number of groups of
+    // kblocks workgroups, no more groups than items
+    const int lds_bytes = (C / CK) * A_CHUNK;
+    int wgs_per_cu = (160 * 1024) / lds_bytes;
+    if (wgs_per_cu > 3) wgs_per_cu = 3;
+    if (wgs_per_cu < 1) wgs_per_cu = 1;
+    int per_xcd = cus * wgs_per_cu / 8 / kblocks;
     if (per_xcd < 1) per_xcd = 1;
     const int64_t need = vo_ceil_div(items, 8);
     if (per_xcd > need) per_xcd = (int)need;

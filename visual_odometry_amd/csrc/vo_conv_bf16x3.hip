@@ -922,8 +922,18 @@ extern "C" int vo_gru_conv_q_bf16x3(const float* x, const float* rh, const void*
     return gru_conv("vo_gru_conv_q_bf16x3", x, arranged, h_out, (int64_t)C * H * W, bias, gru, N, Cin, H, W, C, shape, vo_stream(stream));
 }
 
+// vo_conv1x1_stream.hip: the same layer with the channel block's weights resident in LDS (same weights image, same bits);
+// VO_HIP_CONV1X1_TEMPLATE=1 in the environment keeps the layer on this file's template (for comparisons)
+bool vo_conv1x1_stream_fits(int C, int64_t P, int K);
+int vo_conv1x1_stream_launch(const char* name, const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
+                             const float* shift, int relu, int N, int C, int64_t P, int K, hipStream_t st);
+
 extern "C" int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
                                  const float* shift, int relu, int N, int C, int H, int W, int K, void* stream) {
+    if (H > 0 && W > 0 && vo_conv1x1_stream_fits(C, (int64_t)H * W, K) && ((reinterpret_cast<uintptr_t>(arranged) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+        (y_batch_stride & 3) == 0 && !getenv("VO_HIP_CONV1X1_TEMPLATE"))
+        return vo_conv1x1_stream_launch("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, N, C, (int64_t)H * W, K,
+                                        vo_stream(stream));
     if (narrow_blocks_fit_better(H, W))
         return launch_conv<Geo1x1n>("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, nullptr, nullptr, nullptr,
                                     0.0f, N, C, H, W, K, vo_stream(stream));
