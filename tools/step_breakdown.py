@@ -24,7 +24,7 @@ groups = [("vo_conv3x3_bf16x3", r"conv_bf16x3_kernel<.*Geo<3, 3, 1, 4, (32|16)>,
           ("vo_gru_conv_zr/q_bf16x3", r"conv_bf16x3_kernel<.*Geo<.*>, false, 2, true, false>"),
           ("vo_conv5_bf16x3", r"conv_bf16x3_kernel<.*Geo<(1, 5|5, 1), 1, 4, (32|16)>, (true|false), [12], false, false>"),
           ("vo_conv3x3s2[_shortcut]_bf16x3", r"conv_bf16x3_kernel<.*Geo<3, 3, 2"), ("vo_conv1x1s2_bf16x3", r"conv_bf16x3_kernel<.*Geo<1, 1, 2"),
-          ("vo_conv1x1[_pixel_major]_bf16x3", r"conv_bf16x3_kernel<.*Geo<1, 1, 1"), ("vo_conv7x7_bf16x3", r"conv7_split_kernel"),
+          ("vo_conv1x1[_pixel_major]_bf16x3", r"conv_bf16x3_kernel<.*Geo<1, 1, 1|conv1x1_stream_kernel"), ("vo_conv7x7_bf16x3", r"conv7_split_kernel"),
           ("vo_conv1x1 / _pixel_major / taps", r"conv1x1_kernel"), ("vo_instance_norm_apply", r"instnorm_apply_kernel"),
           ("vo_corr_volume_2d_bf16x3", r"corr_abt_kernel<128"), ("vo_corr_volume_2d_presplit", r"corr_presplit_big_kernel"), ("vo_corr_volume_1d_bf16x3", r"corr_abt_kernel<160"),
           ("vo_corr_pyramid_2d", r"pyramid2d_kernel"), ("vo_corr_lookup_2d", r"lookup2d_kernel"), ("vo_corr_lookup_1d", r"lookup1d_kernel")]
