@@ -211,8 +211,8 @@ int vo_conv3x3s2_shortcut_bf16x3(const float* x, const void* arranged, const voi
 int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
 /* ... and the stride-1 1x1 convolution with many input and output channels (the motion encoders' first layer on the
  * correlation window, the mask heads), where the float32 matrix instruction, not memory, bounds vo_conv1x1:
- * same weights, epilogue (scale / shift / ReLU) and channel-slice output as vo_conv3x3_bf16x3.  Layers with whole blocks
- * of 64 output channels, planes of whole groups of four pixels and 16-byte aligned tensors run on a kernel that keeps
+ * same weights, epilogue (scale / shift / ReLU) and channel-slice output as vo_conv3x3_bf16x3.  Layers with at least
+ * 64 output channels in multiples of 8, planes of whole groups of four pixels and 16-byte aligned tensors run on a kernel that keeps
  * a block's weights in LDS (same bits in the result); VO_HIP_CONV1X1_TEMPLATE=1 in the environment keeps them on the
  * template's kernel (a switch for comparisons). */
 int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,

@@ -1166,7 +1166,7 @@ def test_split_bf16_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
 
 
 def test_streaming_conv1x1_equals_the_template_kernel_bit_for_bit(vo):
-    """Layers with whole blocks of 64 output channels and planes of whole groups of four pixels run on the kernel that
+    """Layers with at least 64 output channels in multiples of 8 and planes of whole groups of four pixels run on the kernel that
     keeps the weights in LDS; VO_HIP_CONV1X1_TEMPLATE=1 keeps them on the convolution template.  Same weights image,
     same order of terms: the results are the same bits -- checked over repeated runs (the two waves a SIMD holds
     run independently of each other), many channel counts (few and many chunks, odd and even), planes smaller than
@@ -1175,7 +1175,8 @@ def test_streaming_conv1x1_equals_the_template_kernel_bit_for_bit(vo):
     from visual_odometry_amd import ops
     rnd = random.Random(5)
     shapes = [(2, 64, 60, 80, 64), (1, 128, 120, 160, 256), (2, 112, 120, 160, 256), (3, 336, 60, 80, 256), (2, 256, 60, 80, 576),
-              (2, 64, 8, 6, 128), (24, 336, 60, 80, 256), (5, 576, 30, 40, 64), (7, 608, 15, 20, 192), (3, 80, 33, 44, 320)]
+              (2, 64, 8, 6, 128), (24, 336, 60, 80, 256), (5, 576, 30, 40, 64), (7, 608, 15, 20, 192), (3, 80, 33, 44, 320),
+              (3, 256, 120, 160, 144), (2, 128, 17, 20, 72), (1, 96, 9, 12, 200)]          # last channel block partial
     shapes += [(rnd.randint(1, 5), 16 * rnd.randint(4, 38), rnd.randint(1, 70), 4 * rnd.randint(1, 40), 64 * rnd.randint(1, 9)) for _ in range(14)]
 
     def template(fn):

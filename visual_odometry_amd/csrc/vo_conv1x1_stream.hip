@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const flo
 
         // C/D layout of a 32x32 tile: pixel = lane & 31 (pixel p0 + t of this lane in tile t), channel row =
         // (e & 3) + 8*(e >> 2) + 4*(lane >> 5).  A lane stores NTL consecutive pixels of a channel at once (the host
-        // admits only planes of whole groups of four pixels, 16-byte aligned outputs and whole channel blocks).
+        // admits only planes of whole groups of four pixels, 16-byte aligned outputs and channel counts in multiples of 8).
         // The lane's part of the address is the same for every channel row (pixels past the plane carry an offset
         // past the extent, which the range check drops); the row's part is uniform and rides in the scalar offset.
         const __amdgpu_buffer_rsrc_t yrs =
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const flo
                     if (ep.relu) v = fmaxf(v, 0.0f);
                     o[t] = __float_as_uint(v);
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(o, yrs, y_off, ku * P * 4, 0);
+                // K is a multiple of 8: the rows ku and ku + 4 of a lane pair are both inside or both outside
+                if (ku < K) __builtin_amdgcn_raw_buffer_store_b64(o, yrs, y_off, ku * P * 4, 0);
             }
         }
     }
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const flo
 // Whether the layer fits this kernel: the weights of a channel block in LDS, 32-bit byte offsets inside one image
 // (two chunks past its end included).
 bool vo_conv1x1_stream_fits(int C, int64_t P, int K) {
-    return C % CK == 0 && C >= 64 && K % KB == 0 && P % 4 == 0 && (int64_t)(C / CK) * A_CHUNK <= 156 * 1024 && ((int64_t)C + 2 * CK + 8) * P * 4 < 0x7fffffffLL &&
+    return C % CK == 0 && C >= 64 && K >= 64 && K % 8 == 0 && P % 4 == 0 && (int64_t)(C / CK) * A_CHUNK <= 156 * 1024 && ((int64_t)C + 2 * CK + 8) * P * 4 < 0x7fffffffLL &&
            (int64_t)K * P * 4 < 0x7fffffffLL;
 }
 

@@ -67,6 +67,9 @@ def conv_plain(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
             U = _winograd_filter_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if U is not None:
                 return ops.conv3x3_winograd(x, U, conv.out_channels, None, conv.bias, False)
+            Ws = _conv1x1_split_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if Ws is not None:                                   # many channels on both sides (the mask heads' last layer)
+                return ops.conv1x1_split(x, Ws, conv.out_channels, None, conv.bias, False)
             Wg = _conv1x1_weights_for(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
             if Wg is not None:
                 return ops.conv1x1(x, Wg, conv.out_channels, None, conv.bias, False)
