@@ -11,10 +11,14 @@
 // eight channels of NTL consecutive pixels), splits it in registers, and keeps the next chunk's loads in flight
 // while it multiplies.  The workgroups of the channel blocks of one layer walk the same pixel tiles at the same
 // time and sit on the same XCD, so the input is read from memory once.
-// (A variant with 128 pixels per wave, 230-256 vector registers, was faster still on the widest layer but returned
-// sporadically wrong accumulator values with 8 waves per workgroup; the cause was not found.  This form, 134
-// registers, equals the template's kernel bit for bit on every shape tried; tests/test_raft_ops_gpu.py keeps
-// comparing the two.)
+// The stores are 8 bytes wide ON PURPOSE.  A 16-byte buffer store whose offset rides in the scalar operand
+// (raw_buffer_store_b128 with a non-constant soffset) may be followed at once by a vector instruction that
+// overwrites its data registers: the compiler inserts the wait states this needs only when the scalar offset is a
+// constant, and on gfx950 the store then writes the NEW register contents for the lanes it reads last (measured: a
+// variant with four pixels per lane returned sporadically wrong values -- the first data register, lanes 12-15 of
+// each row of 16 -- with the scalar offset, none with the same offset folded into the lane offset).  Stores of at
+// most 8 bytes are not affected; every 16-byte buffer store of this library passes a constant 0 as scalar offset.
+// tests/test_raft_ops_gpu.py keeps this kernel under a bit-for-bit comparison with the template's.
 #include "vo_common.h"
 
 namespace {
