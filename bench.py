@@ -46,6 +46,18 @@ SPLIT_BF16_KERNELS = ("vo_conv3x3_bf16x3", "vo_conv5_bf16x3", "vo_conv3x3s2_bf16
                       "vo_corr_volume_2d_bf16x3", "vo_corr_volume_1d_bf16x3", "vo_corr_volume_2d_presplit")
 
 
+DTYPE_TEXT = {
+    "f32": "f32 (every product on the float32 matrix instruction; Winograd forms for the 3x3 and 1x5/5x1 layers)",
+    "f16x3": "f32 (tensors, accumulation and every other operator in float32; each product of the 3x3, 1x5/5x1, stride-2, "
+             "many-channel 1x1 and 7x7 convolutions (GRU gate convolutions included) is three float16 matrix-core terms on "
+             "operands cut into two float16 pieces: 22 significant bits per operand, exact power-of-two scaling for the "
+             "exponent range, |x| > 65504 -> NaN; measured error of a layer = the float32 matrix instruction's; the "
+             "correlation volumes run on the float32 matrix instruction itself; see f32_mfma_only and bf16x3 beside it)",
+    "bf16x3": "f32 tensors and accumulation; heavy products (convolutions and correlation volumes) from three bf16 "
+              "matrix-core terms, 16 significant bits per operand: narrower than the reference's float32",
+}
+
+
 def algorithmic_work(B: int, H: int, W: int, iters: int, n_kp: int, D: int = 256):
     """Per-STEP algorithmic bytes / FLOPs and launch counts of every hand-written
     kernel for B frame pairs (= B new stereo frames + B flow pairs)."""
@@ -137,37 +149,48 @@ def _time(fn, repeat):
 
 
 def cpu_baseline(vo, left, right, iters, threads, stereo_name):
-    """The CPU oracle (kind "port": stock-PyTorch RAFT restatement + NumPy geometry) on this box's
-    host cores, on a bounded sample of the same workload.  The headline figure is one steady-state
-    frame pair (1 new stereo frame + 1 flow pair + geometry with the reference's per-point loop)
-    with ``threads`` threads, averaged over 3 pairs after a warm-up; beside it the single-thread
-    figure and the geometry / pose / composition stages on their own."""
-    from oracle import geometry_ref, raft_ref
-    flow_m = copy.deepcopy(vo.flow_solver.model).cpu().eval()
-    stereo_m = copy.deepcopy(vo.disparity_solver.model).cpu().eval()
+    """The CPU oracle (kind "port": the stock-PyTorch restatement of RAFT / RAFT-Stereo in oracle/raft_modules.py
+    carrying the GPU run's weights, + NumPy geometry with the reference's per-point loop) on this box's host cores, on
+    a bounded sample of the same workload.  The headline figure: 20 steady-state frame pairs (1 new stereo frame + 1
+    flow pair + geometry each, four pairs per forward pass) after 3 warm-up pairs, all ``threads`` threads, with the
+    argument set of the GPU run; beside it the same for the reference's default (full) RAFT-Stereo arguments, one pair
+    on one thread for both, and the geometry / pose / composition stages on their own."""
+    from oracle import geometry_ref, raft_modules
+    flow_m = raft_modules.flow_twin(vo.flow_solver.model, "cpu")
+    stereo_models = {stereo_name: raft_modules.stereo_twin(vo.disparity_solver.model, "cpu")}
+    other = "full" if stereo_name == "realtime" else "realtime"
+    torch.manual_seed(1)
+    stereo_models[other] = (raft_modules.RAFTStereo() if other == "full"
+                            else raft_modules.RAFTStereo(hidden_dims=(64, 64, 64), n_gru_layers=2)).eval()
     rgb = lambda a: a.float()[:, None].expand(-1, 3, -1, -1).contiguous().cpu()
-    n_pairs = 3
-    l, r = rgb(left[:n_pairs + 1]), rgb(right[:n_pairs + 1])
-    small = torch.rand(1, 3, 64, 96) * 255
+    group, n_groups, n_warm = 4, 5, 3
+    l, r = rgb(left[:group + 1]), rgb(right[:group + 1])
+    small = torch.rand(1, 3, 128, 160) * 255
     K_inv = vo.pts_xform.K_inv
     kp = vo.pts_src.get_keypoints(None, vo.cfg.max_keypoints)
     H, W = left.shape[1:]
 
-    def networks(n):
+    def networks(stereo_m, n):
         """n steady-state pairs: stereo on frames 1..n, flow on pairs (0,1)..(n-1,n)."""
         t0 = time.perf_counter()
-        _, disp = raft_ref.raft_stereo_forward(stereo_m, l[1:n + 1], r[1:n + 1], iters)
+        _, disp = stereo_m(l[1:n + 1], r[1:n + 1], iters)
         t1 = time.perf_counter()
-        _, flow = raft_ref.raft_flow_forward(flow_m, l[:n], l[1:n + 1], iters)
+        _, flow = flow_m(l[:n], l[1:n + 1], iters)
         return t1 - t0, time.perf_counter() - t1, disp, flow
 
     torch.set_num_threads(threads)
-    raft_ref.raft_flow_forward(flow_m, small, small, 1)              # thread-pool / allocator warm-up
-    raft_ref.raft_stereo_forward(stereo_m, small, small, 1)
-    networks(1)
-    ts, tf, disp, flow = networks(n_pairs)
-    t_stereo, t_flow = ts / n_pairs, tf / n_pairs
-    depth = [geometry_ref.disparity_to_depth(disp[i, 0].numpy(), vo._fxB, 1.0) for i in range(n_pairs)]
+    flow_m(small, small, 1)                                           # thread-pool / allocator warm-up
+    legs = {}
+    for name, stereo_m in stereo_models.items():
+        stereo_m(small, small, 1)
+        networks(stereo_m, n_warm)
+        ts = tf = 0.0
+        for _ in range(n_groups):
+            a, b, disp, flow = networks(stereo_m, group)
+            ts, tf = ts + a, tf + b
+        legs[name] = (ts / (group * n_groups), tf / (group * n_groups), disp, flow)
+    t_stereo, t_flow, disp, flow = legs[stereo_name]
+    depth = [geometry_ref.disparity_to_depth(disp[i, 0].numpy(), vo._fxB, 1.0) for i in range(2)]
     flow_np = flow.numpy()
     geo = lambda loop: geometry_ref.pair_pose(kp, depth[0], depth[1], flow_np[1], K_inv, loop=loop)
     t_geo_loop = _time(lambda: (geometry_ref.disparity_to_depth(disp[1, 0].numpy(), vo._fxB, 1.0), geo(True)), 5)
@@ -175,9 +198,12 @@ def cpu_baseline(vo, left, right, iters, threads, stereo_name):
     per_pair = t_stereo + t_flow + t_geo_loop
 
     torch.set_num_threads(1)
-    ts1, tf1, _, _ = networks(1)
+    single = {}
+    for name, stereo_m in stereo_models.items():
+        a, b, _, _ = networks(stereo_m, 1)
+        single[name] = (a, b)
     torch.set_num_threads(threads)
-    per_pair_1 = ts1 + tf1 + t_geo_loop
+    per_pair_1 = sum(single[stereo_name]) + t_geo_loop
 
     # the dense 1280x720 grid (19 928 points): geometry only, synthetic maps
     rng = np.random.default_rng(0)
@@ -196,18 +222,31 @@ def cpu_baseline(vo, left, right, iters, threads, stereo_name):
     # host composition of 100 000 relative poses (test_camera_tracking.py:210)
     Tn = np.tile(np.eye(4), (100000, 1, 1))
     t_compose = _time(lambda: geometry_ref.compose_trajectory(Tn), 1)
+    try:
+        import cv2  # noqa: F401
+        sgbm = "cv2 importable but the SGBM leg is not implemented"
+    except ImportError:
+        sgbm = "unavailable: cv2 is not importable on this box (stereo/stereo_disparity_openCV.py:35-47 cannot run), no substitute"
+    o_s, o_f = legs[other][:2]
     return {"value": 1.0 / per_pair, "unit": "frame-pairs/s", "cores": threads, "host_cores": os.cpu_count(),
             "kind": "port",
-            "sample": f"{n_pairs} steady-state frame pairs {W}x{H} after one warm-up pair, {iters} iters: "
-                      f"RAFT-Stereo({stereo_name} args) {t_stereo:.2f}s + RAFT-Flow {t_flow:.2f}s + "
+            "sample": f"{group * n_groups} steady-state frame pairs {W}x{H} ({group} per forward pass) after {n_warm} warm-up pairs, "
+                      f"{iters} iters: RAFT-Stereo({stereo_name} args) {t_stereo:.2f}s + RAFT-Flow {t_flow:.2f}s + "
                       f"geometry (per-point loop) {t_geo_loop * 1e3:.1f}ms per pair, {threads} threads",
             "seconds_per_pair": per_pair,
+            "other_stereo_args": {"value": 1.0 / (o_s + o_f + t_geo_loop), "unit": "frame-pairs/s", "cores": threads,
+                                  "sample": f"same sample with RAFT-Stereo({other} args, default-initialised weights): "
+                                            f"{o_s:.2f}s + RAFT-Flow {o_f:.2f}s per pair"},
             "single_thread": {"value": 1.0 / per_pair_1, "unit": "frame-pairs/s", "cores": 1,
-                              "sample": f"1 frame pair: RAFT-Stereo {ts1:.1f}s + RAFT-Flow {tf1:.1f}s + geometry"},
+                              "sample": f"1 frame pair (20 would take minutes): RAFT-Stereo({stereo_name}) {single[stereo_name][0]:.1f}s + "
+                                        f"RAFT-Flow {single[stereo_name][1]:.1f}s + geometry; RAFT-Stereo({other}) "
+                                        f"{single[other][0]:.1f}s",
+                              "other_stereo_args_value": 1.0 / (sum(single[other]) + t_geo_loop)},
             "geometry_us_per_pair": {"loop_300pts": 1e6 * t_geo_loop, "vectorised_300pts": 1e6 * t_geo_vec,
                                      "loop_19928pts": 1e6 * t_dense_loop, "vectorised_19928pts": 1e6 * t_dense_vec},
             "kabsch_pairs_per_s": {"n300": 1.0 / t_kabsch_300, "n19928": 1.0 / t_kabsch_dense},
-            "compose_100k_poses_ms": 1e3 * t_compose}
+            "compose_100k_poses_ms": 1e3 * t_compose,
+            "sgbm_config1": sgbm}
 
 
 def timed_steps(vo, left, right, cached, steps, warmup):
@@ -272,10 +311,28 @@ def main():
                     help="skip the secondary measurements of the reference's default (full) argument set")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the measurement with frames uploaded from pinned host memory")
     ap.add_argument("--pose", choices=["svd", "ransac"], default="svd")
-    ap.add_argument("--conv-arithmetic", choices=["bf16x3", "f32"], default="bf16x3",
-                    help="how the heavy float32 convolutions multiply: three bf16 matrix-core terms per product "
-                         "(default) or float32 matrix instructions only")
+    ap.add_argument("--conv-arithmetic", choices=["f16x3", "bf16x3", "f32"], default="f16x3",
+                    help="how the heavy float32 products are formed: three float16 matrix-core terms (22 significant "
+                         "bits per operand, the float32 instruction's error; default), three bf16 terms (16 bits), or "
+                         "float32 matrix instructions only")
     args = ap.parse_args()
+
+    # --gpus N without a launcher around this process: start the N ranks here, one fresh process per GPU through
+    # torch.distributed.run, BEFORE this process has touched the GPU (it never does: it only relays the ranks' output
+    # and exit status).  Under a launcher WORLD_SIZE must agree with --gpus.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -302,13 +359,16 @@ def main():
     from visual_odometry_amd.raft.models import RAFTStereoConfig
 
     H, W, B = args.height, args.width, args.batch
+    if shared_card:
+        # a rehearsal of the multi-rank path on a box with fewer GPUs than ranks: the ranks share a card, so each takes
+        # its share of the chunk (the card's memory holds one full chunk, not one per rank)
+        B = max(8, B // -(-local_world // n_dev))
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
-    from visual_odometry_amd.raft import layers as raft_layers
-    raft_layers.conv_arithmetic(args.conv_arithmetic)
     def make_vo(mixed, stereo=args.stereo, iters=args.iters, pose=args.pose):
         cfg = VOConfig(iters=iters,
                        stereo=RAFTStereoConfig.realtime() if stereo == "realtime" else RAFTStereoConfig(),
-                       camera_offset=syn.CAMERA_OFFSET, mixed_precision=mixed, pose=pose)
+                       camera_offset=syn.CAMERA_OFFSET, mixed_precision=mixed, pose=pose,
+                       conv_arithmetic=args.conv_arithmetic)
         return VisualOdometry(cfg, syn.left_K(W / 640.0), syn.focal_length_px() * (W / 640.0), syn.baseline(),
                               np.ones((H, W), bool), seed=0)
 
@@ -452,19 +512,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f16 activations, f32 weights/correlation/geometry" if args.mixed_precision else
-                      ("f32" if args.conv_arithmetic == "f32" else
-                       "f32 (tensors, accumulation and every other operator in float32; the products of the 3x3, 1x5/5x1, "
-                       "stride-2, many-channel 1x1 and one/two-channel 7x7 convolutions (GRU gate convolutions included) and of "
-                       "the correlation volumes are assembled from three bf16 matrix-core terms, 16 significant bits each, "
-                       "measured error below the float32 Winograd kernels' -- see f32_mfma_only for every product on the "
-                       "float32 matrix instruction)")),
+            "dtype": ("f16 activations, f32 weights/correlation/geometry" if args.mixed_precision else DTYPE_TEXT[args.conv_arithmetic]),
             "data": "synthetic",
             "config": {"workload": f"RAFT-Flow + RAFT-Stereo({args.stereo} args) {W}x{H}, {args.iters} iters, "
                                    f"{n_kp} grid keypoints, {'Kabsch' if args.pose == 'svd' else 'RANSAC'} pose; "
                                    f"synthetic stereo frame pairs resident in HBM",
                        "pairs_per_step_per_gpu": B, "pairs_timed": pairs, "iters": args.iters,
-                       "sharding": f"{world} rank(s), contiguous pair ranges, no data-path collective",
+                       "sharding": f"{world} rank(s), contiguous pair ranges, no data-path collective" +
+                                   (f"; REHEARSAL: {local_world} ranks share {n_dev} GPU(s), gloo rendezvous" if shared_card else ""),
                        "conditions": f"the same {B + 1} frames per rank are re-used by every step and stay resident in "
                                      f"HBM; the PCIe upload is outside value (with_upload reports it inside); no "
                                      f"graph capture; pose gather + composition outside the timed region (gather)"},
@@ -493,16 +548,23 @@ def main():
                                   "note": "frames from pinned host memory, chunk k+1 uploaded on a second stream "
                                           "while chunk k computes; includes the first chunk's halo stereo frame"}
             del lh, rh
-        if world == 1 and not args.mixed_precision and args.conv_arithmetic == "bf16x3" and not args.no_config_legs:
-            # the same step with float32 matrix instructions only (the Winograd kernels)
-            raft_layers.conv_arithmetic("f32")
-            try:
-                dt32 = timed_steps(vo, left, right, cached, max(1, min(args.steps, 3)), 1)
-            finally:
-                raft_layers.conv_arithmetic("bf16x3")
-            out["f32_mfma_only"] = {"value": B / dt32, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt32, "dtype": "f32",
-                                    "note": "every convolution on float32 matrix instructions (v_mfma_f32_32x32x2_f32), "
-                                            "which run at the vector rate, 1/16 of the bf16 matrix rate"}
+        if world == 1 and not args.mixed_precision and not args.no_config_legs:
+            # the same step, same pipeline object, under the other product arithmetics
+            notes = {"f32": "every product on float32 matrix instructions (v_mfma_f32_32x32x2_f32), which run at the vector "
+                            "rate, 1/16 of the 16-bit matrix rate",
+                     "bf16x3": "three bf16 matrix-core terms per product (16 significant bits per operand), correlation "
+                               "volumes included: narrower than the reference's float32, reported beside the metric",
+                     "f16x3": "three float16 matrix-core terms per product (22 significant bits per operand)"}
+            for kind, key in (("f32", "f32_mfma_only"), ("bf16x3", "bf16x3"), ("f16x3", "f16x3")):
+                if kind == args.conv_arithmetic:
+                    continue
+                vo.set_conv_arithmetic(kind)
+                try:
+                    dt_k = timed_steps(vo, left, right, cached, max(1, min(args.steps, 3)), 1)
+                finally:
+                    vo.set_conv_arithmetic(args.conv_arithmetic)
+                out[key] = {"value": B / dt_k, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt_k, "dtype": DTYPE_TEXT[kind],
+                            "note": notes[kind]}
         if world == 1 and not args.mixed_precision and not args.no_mixed_precision_leg:
             out["mixed_precision"] = mixed_precision_leg(vo, make_vo(True), left, right, cached, args.steps)
         if world == 1 and not args.no_cpu_baseline:

@@ -32,7 +32,11 @@ extern "C" {
 
 #define VO_MAX_LEVELS 4          /* corr_levels=4: stereo/stereo_disparity_RAFT.py:40 */
 
-/* Library version as major*10000 + minor*100 + patch. */
+/* Library version as major*10000 + minor*100 + patch; it changes whenever an entry point's signature does.
+ * VO_HIP_VERSION is the version this header describes: a caller compares vo_version() with it (or with the
+ * value its own binding was written for) before the first call, because a library built from another header
+ * would take shifted arguments without any error. */
+#define VO_HIP_VERSION 300
 int vo_version(void);
 /* Message for the last non-zero status returned on this thread ("" if none). */
 const char* vo_last_error(void);
@@ -160,8 +164,24 @@ int vo_conv3x3_winograd4(const float* x, const float* transformed, float* y, int
                          double* stats, const double* in_stats, float in_eps,
                          int N, int C, int H, int W, int K, void* stream);
 
+/* Which 16-bit format the split convolutions below cut a float32 operand into (their ``pieces`` argument), and the
+ * power of two that goes with float16 pieces (``weight_exp``):
+ *   VO_PIECES_BF16  x = xh + xl, both bf16: 16 significant bits per operand, float32's exponent range; largest error
+ *                   4-6e-6 of a layer's largest output.  weight_exp must be 0.
+ *   VO_PIECES_F16   both float16: 22 significant bits per operand; the error of a layer is that of the float32 matrix
+ *                   instruction (the float32 accumulation dominates).  float16's exponent range is met with exact powers
+ *                   of two: the *_filter call multiplies the weights by 2^weight_exp before cutting them (the caller
+ *                   picks weight_exp so that max|w| * 2^weight_exp lies in [2^13, 2^14) and passes the same value to the
+ *                   convolution, which multiplies its accumulators by 2^-weight_exp); an input's low part is kept 2^11
+ *                   times too large and meets weights scaled by 2^-11.  Inputs keep 22 bits for 6.1e-5 <= |x| <= 65504
+ *                   and an absolute error below 2^-36 under that; |x| > 65504 yields NaN, never a wrong number.
+ * The reference runs float32 throughout (mixed_precision=False: flow/flow_map_RAFT.py:38,
+ * stereo/stereo_disparity_RAFT.py:43); VO_PIECES_F16 is the arithmetic that stands for it, VO_PIECES_BF16 the faster,
+ * narrower one.  Same instruction count, same kernels, same layouts either way. */
+enum { VO_PIECES_BF16 = 0, VO_PIECES_F16 = 1 };
+
 /* The same convolution (3x3, stride 1, padding 1, float32 in and out, NCHW) as a direct sum on
- * the bf16 matrix cores with every float32 product assembled from bf16 pieces: x = xh + xl,
+ * the bf16 / float16 matrix cores with every float32 product assembled from 16-bit pieces: x = xh + xl,
  * w = wh + wl (high part = the value rounded to bf16, low part = the rounded rest), and
  * x*w ~ xl*wh + xh*wl + xh*wh with float32 accumulation.  Each product keeps 16 significant bits;
  * the largest error on the networks' layers is 4-6e-6 of the largest output (the F(4x4,3x3) kernel
@@ -171,11 +191,11 @@ int vo_conv3x3_winograd4(const float* x, const float* transformed, float* y, int
  *                             ceil(K/64)*64 * C * 9 * 4 BYTES.  C must be a multiple of 16.
  *   vo_conv3x3_bf16x3         arguments, epilogue, statistics and normalise-on-load exactly as
  *                             vo_conv3x3_winograd.  W must be even, x 8-byte aligned. */
-int vo_conv3x3_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv3x3_bf16x3_filter(const float* weight, void* arranged, int K, int C, int pieces, int weight_exp, void* stream);
 int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
                       const float* scale, const float* shift, int relu, const float* skip,
                       double* stats, const double* in_stats, float in_eps,
-                      int N, int C, int H, int W, int K, void* stream);
+                      int N, int C, int H, int W, int K, int pieces, int weight_exp, void* stream);
 
 /* The same split-bf16 arithmetic for the two other heavy layer types (one kernel template):
  *   vo_conv5_bf16x3      1x5 (padding (0,2)) / 5x1 (padding (2,0)) stride-1 convolution, the gate
@@ -186,13 +206,13 @@ int vo_conv3x3_bf16x3(const float* x, const void* arranged, float* y, int64_t y_
  *                        -> y (N,K,(H-1)/2+1,(W-1)/2+1); weights from vo_conv3x3_bf16x3_filter; optional
  *                        epilogue as above, or stats (N,K,2) float64 as vo_conv3x3_winograd's.
  * C a multiple of 16, W even, x 8-byte aligned. */
-int vo_conv5_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv5_bf16x3_filter(const float* weight, void* arranged, int K, int C, int pieces, int weight_exp, void* stream);
 int vo_conv5_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
                     const float* scale, const float* shift, int relu,
-                    int N, int C, int H, int W, int K, int vertical, void* stream);
+                    int N, int C, int H, int W, int K, int vertical, int pieces, int weight_exp, void* stream);
 int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
-                        int N, int C, int H, int W, int K, void* stream);
+                        int N, int C, int H, int W, int K, int pieces, int weight_exp, void* stream);
 /* A downsampling residual block's two convolutions of its input in ONE pass (flow/flow_map_RAFT.py:42 and
  * stereo/stereo_disparity_RAFT.py:46 construct the encoders whose stride-2 stages hold them): the 3x3 stride-2
  * convolution (weights from vo_conv3x3_bf16x3_filter) and the 1x1 stride-2 projection shortcut (weights from
@@ -200,37 +220,39 @@ int vo_conv3x3s2_bf16x3(const float* x, const void* arranged, float* y,
  * tap, so the patch staged for the one serves the other: one more tap of matrix instructions per chunk instead of a second
  * kernel that reads and stages x again.  Per output its own epilogue (scale / shift / ReLU, folded batch norm) or its own
  * plane sums (stats, stats2: float64 (N,K,2), zeroed by the caller; no epilogue with them).  Needs an even W, an output
- * width in multiples of 4 and 16-byte aligned outputs (dense (N,K,ceil(H/2),ceil(W/2))). */
+ * width in multiples of 4 and 16-byte aligned outputs (dense (N,K,ceil(H/2),ceil(W/2))).  weight_exp / weight_exp_1x1:
+ * the exponents of the two weight images (float16 pieces). */
 int vo_conv3x3s2_shortcut_bf16x3(const float* x, const void* arranged, const void* arranged1x1, float* y, float* y2,
                                  const float* scale, const float* shift, int relu, double* stats,
                                  const float* scale2, const float* shift2, int relu2, double* stats2,
-                                 int N, int C, int H, int W, int K, void* stream);
+                                 int N, int C, int H, int W, int K, int pieces, int weight_exp, int weight_exp_1x1, void* stream);
 /* The 1x1 stride-2 convolution of the residual stages' projection shortcuts on the same template (it reads
  * only the rows the stride lands on): weights (K,C) from vo_conv1x1_bf16x3_filter (ceil(K/64)*64 * C * 4 bytes),
  * epilogue or stats as vo_conv3x3s2_bf16x3. */
-int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, int pieces, int weight_exp, void* stream);
 /* ... and the stride-1 1x1 convolution with many input and output channels (the motion encoders' first layer on the
  * correlation window, the mask heads), where the float32 matrix instruction, not memory, bounds vo_conv1x1:
  * same weights, epilogue (scale / shift / ReLU) and channel-slice output as vo_conv3x3_bf16x3.  Layers with at least
  * 64 output channels in multiples of 8, planes of whole groups of four pixels and 16-byte aligned tensors run on a kernel that keeps
- * a block's weights in LDS (same bits in the result); VO_HIP_CONV1X1_TEMPLATE=1 in the environment keeps them on the
- * template's kernel (a switch for comparisons). */
+ * a block's weights in LDS (bf16 pieces; same bits in the result); use_template != 0 keeps them on the template's kernel
+ * (a switch for comparing the two). */
 int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
                       const float* scale, const float* shift, int relu,
-                      int N, int C, int H, int W, int K, void* stream);
+                      int N, int C, int H, int W, int K, int pieces, int weight_exp, int use_template, void* stream);
 /* vo_conv1x1_bf16x3 with y written pixel-major, (N, H*W, K) (K a multiple of 4): the feature encoders' last layer in the
  * layout the correlation kernels read (cf. vo_conv1x1_pixel_major). */
 int vo_conv1x1_pixel_major_bf16x3(const float* x, const void* arranged, float* y,
                                   const float* scale, const float* shift, int relu,
-                                  int N, int C, int H, int W, int K, void* stream);
+                                  int N, int C, int H, int W, int K, int pieces, int weight_exp, void* stream);
 /* vo_conv1x1_pixel_major_bf16x3 whose rows leave as bf16 pieces in blocks of 32 channels (K a multiple of 32): the
- * input form of vo_corr_volume_2d_presplit, see vo_split_feature_rows.  y holds N*H*W*K*4 bytes. */
+ * input form of vo_corr_volume_2d_presplit, see vo_split_feature_rows.  y holds N*H*W*K*4 bytes.  bf16 pieces only
+ * (weights from vo_conv1x1_bf16x3_filter with VO_PIECES_BF16). */
 int vo_conv1x1_split_rows_bf16x3(const float* x, const void* arranged, void* y,
                                  const float* scale, const float* shift, int relu,
                                  int N, int C, int H, int W, int K, void* stream);
 int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y,
                         const float* scale, const float* shift, int relu, double* stats,
-                        int N, int C, int H, int W, int K, void* stream);
+                        int N, int C, int H, int W, int K, int pieces, int weight_exp, void* stream);
 /* One step of a convolutional GRU (RAFT's SepConvGRU halves, RAFT-Stereo's ConvGRU; the update operators of the
  * models built at flow/flow_map_RAFT.py:42 and stereo/stereo_disparity_RAFT.py:46) as TWO convolutions on the
  * split-bf16 template with the gate arithmetic in their stores -- no pointwise pass, no concatenation:
@@ -246,10 +268,11 @@ int vo_conv1x1s2_bf16x3(const float* x, const void* arranged, float* y,
  * every tensor 16-byte aligned, batch strides multiples of 4.  Replaces vo_conv* + vo_gru_gates / vo_gru_update. */
 int vo_gru_conv_zr_bf16x3(const float* x, const void* arranged, const float* bias, const float* cz, int64_t cz_batch_stride,
                           const float* cr, int64_t cr_batch_stride, const float* h, int64_t h_batch_stride, float* z_out,
-                          float* rh_out, int N, int Cin, int H, int W, int C, int shape, void* stream);
+                          float* rh_out, int N, int Cin, int H, int W, int C, int shape, int pieces, int weight_exp, void* stream);
 int vo_gru_conv_q_bf16x3(const float* x, const float* rh, const void* arranged, const float* bias, const float* cq,
                          int64_t cq_batch_stride, const float* z, const float* h, int64_t h_batch_stride, float* h_out,
-                         float* h_copy, int64_t copy_batch_stride, int N, int Cin, int H, int W, int C, int shape, void* stream);
+                         float* h_copy, int64_t copy_batch_stride, int N, int Cin, int H, int W, int C, int shape,
+                         int pieces, int weight_exp, void* stream);
 
 /* 7x7 padding-3 convolution (stride 1 or 2) of a ONE- or TWO-channel input in the same arithmetic: the encoders'
  * stems on a gray frame (the wrappers' three equal channels folded into one, flow/flow_map_RAFT.py:96,101-102)
@@ -259,9 +282,9 @@ int vo_gru_conv_q_bf16x3(const float* x, const float* rh, const void* arranged, 
  *   vo_conv7x7_bf16x3_filter  weight (K,C,7,7) -> ceil(K/64)*64 * C * 64 * 4 bytes in operand order.
  *   vo_conv7x7_bf16x3         x (N,C,H,W) -> y (N,K,Ho,Wo), Ho = (H-1)/stride + 1; epilogue v*scale[k] + shift[k]
  *                             (either may be NULL), ReLU -- or stats, then no epilogue. */
-int vo_conv7x7_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream);
+int vo_conv7x7_bf16x3_filter(const float* weight, void* arranged, int K, int C, int pieces, int weight_exp, void* stream);
 int vo_conv7x7_bf16x3(const float* x, const void* arranged, float* y, const float* scale, const float* shift, int relu,
-                      double* stats, int N, int C, int H, int W, int K, int stride, void* stream);
+                      double* stats, int N, int C, int H, int W, int K, int stride, int pieces, int weight_exp, void* stream);
 
 /* 1x5 (padding (0,2)) and 5x1 (padding (2,0)) stride-1 float32 convolutions, NCHW, no bias, as
  * one-dimensional Winograd F(4,5) on the matrix cores: the gate convolutions of the separable

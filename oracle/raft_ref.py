@@ -142,58 +142,32 @@ def unpad(x: torch.Tensor, pads):
 
 
 # ------------------------------------------------------------ whole networks
-# The conv encoders / GRUs are ordinary PyTorch modules and are shared with the
-# product (they "stay PyTorch"); these forwards re-run them with the stock-op
-# correlation path above, on whatever device the module lives on (CPU for the
-# baseline).  Same iteration structure as the published test_mode forward.
+# The module trees (encoders, motion encoders, GRUs, heads) are restated with stock PyTorch
+# operators in oracle/raft_modules.py; nothing of the product's network code runs here.  A model
+# handed to these functions only lends its configuration and its ``state_dict()``, which is loaded
+# (strict) into the restated tree on the device and in the dtype float32 the restatement runs in.
+
+def _twin(model, make, device):
+    from . import raft_modules
+    if isinstance(model, (raft_modules.RAFT, raft_modules.RAFTStereo)):
+        return model
+    key = tuple((k, v._version, v.data_ptr()) for k, v in model.state_dict().items())
+    cached = getattr(model, "_oracle_twin", None)
+    if cached is None or cached[0] != (key, str(device)):
+        cached = ((key, str(device)), make(model, device))
+        object.__setattr__(model, "_oracle_twin", cached)
+    return cached[1]
+
 
 @torch.no_grad()
 def raft_flow_forward(model, image1, image2, iters=12):
-    c = model.cfg
-    image1 = 2 * (image1 / 255.0) - 1.0
-    image2 = 2 * (image2 / 255.0) - 1.0
-    fmap1, fmap2 = model.fnet(torch.cat([image1, image2], 0)).float().chunk(2, dim=0)
-    pyr = corr_pyramid_2d(corr_volume_2d(fmap1, fmap2), c.corr_levels)
-    net, inp = torch.split(model.cnet(image1), [c.hidden_dim, c.context_dim], dim=1)
-    net, inp = torch.tanh(net), torch.relu(inp)
-    B, _, H, W = image1.shape
-    coords0 = coords_grid(B, H // 8, W // 8, image1.device)
-    coords1 = coords0.clone()
-    mask = None
-    for it in range(iters):
-        window = corr_lookup_2d(pyr, coords1, c.corr_radius)
-        net, mask, delta = model.update_block(net, inp, window, coords1 - coords0, want_mask=(it == iters - 1))
-        coords1 = coords1 + delta
-    return coords1 - coords0, convex_upsample(coords1 - coords0, 0.25 * mask, 8)
+    """(flow at 1/8 resolution, full-resolution flow) from the restated RAFT carrying ``model``'s weights."""
+    from . import raft_modules
+    return _twin(model, raft_modules.flow_twin, image1.device)(image1.float(), image2.float(), iters)
 
 
 @torch.no_grad()
 def raft_stereo_forward(model, image1, image2, iters=12):
-    c = model.cfg
-    image1 = 2 * (image1 / 255.0) - 1.0
-    image2 = 2 * (image2 / 255.0) - 1.0
-    cnet_list = model.cnet(image1, num_layers=c.n_gru_layers)
-    fmap1, fmap2 = model.fnet(torch.cat([image1, image2], 0)).float().chunk(2, dim=0)
-    net_list = [torch.tanh(x[0]) for x in cnet_list]
-    inp_list = [torch.relu(x[1]) for x in cnet_list]
-    inp_list = [list(conv(i).split(split_size=conv.out_channels // 3, dim=1))
-                for i, conv in zip(inp_list, model.context_zqr_convs)]
-    pyr = corr_pyramid_1d(corr_volume_1d(fmap1, fmap2), c.corr_levels)
-    B, _, h, w = net_list[0].shape
-    coords0 = coords_grid(B, h, w, image1.device)
-    coords1 = coords0.clone()
-    mask = None
-    for it in range(iters):
-        window = corr_lookup_1d(pyr, coords1, c.corr_radius)
-        flow = coords1 - coords0
-        if c.n_gru_layers == 3 and c.slow_fast_gru:
-            net_list = model.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
-        if c.n_gru_layers >= 2 and c.slow_fast_gru:
-            net_list = model.update_block(net_list, inp_list, iter32=c.n_gru_layers == 3, iter16=True,
-                                          iter08=False, update=False)
-        net_list, mask, delta = model.update_block(net_list, inp_list, window, flow, iter32=c.n_gru_layers == 3,
-                                                   iter16=c.n_gru_layers >= 2, want_mask=(it == iters - 1))
-        delta[:, 1] = 0.0
-        coords1 = coords1 + delta
-    up = convex_upsample(coords1 - coords0, 0.25 * mask, 2 ** c.n_downsample)
-    return coords1 - coords0, up[:, :1]
+    """(x-flow field at working resolution, full-resolution disparity) from the restated RAFT-Stereo."""
+    from . import raft_modules
+    return _twin(model, raft_modules.stereo_twin, image1.device)(image1.float(), image2.float(), iters)

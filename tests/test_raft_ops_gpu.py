@@ -718,16 +718,10 @@ def test_networks_agree_with_and_without_the_winograd_kernel(vo, tile):
     torch.manual_seed(11)
     flow, stereo = RAFTFlow().to(DEV).eval(), RAFTStereo(RAFTStereoConfig.realtime()).to(DEV).eval()
     a, b = (_rand(1, 3, 96, 128, seed=60) * 60 + 120).to(DEV), (_rand(1, 3, 96, 128, seed=61) * 60 + 120).to(DEV)
-    try:
-        layers.winograd_enabled(False)
+    with layers.arithmetic(hand_kernels=False):
         f0, d0 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
-    finally:
-        layers.winograd_enabled(True)
-    try:
-        layers.winograd_tile(tile)
+    with layers.arithmetic(winograd_tile=tile):
         f1, d1 = flow(a, b, iters=3)[1], stereo(a, b, iters=3)[1]
-    finally:
-        layers.winograd_tile(0)
     tol = 1e-4 if tile == 2 else 2e-3
     assert (f1 - f0).abs().max().item() < tol and (d1 - d0).abs().max().item() < tol
 
@@ -817,14 +811,10 @@ def test_winograd_normalises_its_input_on_load(vo, tile):
     torch.manual_seed(4)
     blk = ResidualBlock(64, 64, "instance").to(DEV).eval()
     x = torch.relu(_rand(2, 64, 37, 52, seed=97)).to(DEV)
-    try:
-        layers.winograd_tile(tile)
-        with torch.no_grad():
-            a = blk(x)
-            with fused_passes():
-                b = blk(x)
-    finally:
-        layers.winograd_tile(0)
+    with layers.arithmetic(winograd_tile=tile), torch.no_grad():
+        a = blk(x)
+        with fused_passes():
+            b = blk(x)
     assert (a - b).abs().max().item() < (1e-4 if tile == 2 else 5e-4) * max(1.0, a.abs().max().item())
 
 
@@ -1167,7 +1157,7 @@ def test_split_bf16_conv1x1_matches_the_stock_convolution(vo, N, C, H, W, K):
 
 def test_streaming_conv1x1_equals_the_template_kernel_bit_for_bit(vo):
     """Layers with at least 64 output channels in multiples of 8 and planes of whole groups of four pixels run on the kernel that
-    keeps the weights in LDS; VO_HIP_CONV1X1_TEMPLATE=1 keeps them on the convolution template.  Same weights image,
+    keeps the weights in LDS (bf16 pieces); ``use_template`` keeps them on the convolution template.  Same weights image,
     same order of terms: the results are the same bits -- checked over repeated runs (the two waves a SIMD holds
     run independently of each other), many channel counts (few and many chunks, odd and even), planes smaller than
     a wave's share and larger than a tile, the motion encoder's full shape, scale + bias + ReLU, a channel slice."""
@@ -1179,12 +1169,8 @@ def test_streaming_conv1x1_equals_the_template_kernel_bit_for_bit(vo):
               (3, 256, 120, 160, 144), (2, 128, 17, 20, 72), (1, 96, 9, 12, 200)]          # last channel block partial
     shapes += [(rnd.randint(1, 5), 16 * rnd.randint(4, 38), rnd.randint(1, 70), 4 * rnd.randint(1, 40), 64 * rnd.randint(1, 9)) for _ in range(14)]
 
-    def template(fn):
-        os.environ["VO_HIP_CONV1X1_TEMPLATE"] = "1"
-        try:
-            return fn()
-        finally:
-            del os.environ["VO_HIP_CONV1X1_TEMPLATE"]
+    def template(*args, **kw):
+        return ops.conv1x1_split(*args, use_template=True, **kw)
 
     for (N, C, H, W, K) in shapes:
         x = _rand(N, C, H, W, seed=400 + C).to(DEV)
@@ -1196,14 +1182,14 @@ def test_streaming_conv1x1_equals_the_template_kernel_bit_for_bit(vo):
         got = ops.conv1x1_split(x, A, K)
         ops.set_recorder(None)
         assert "vo_conv1x1_bf16x3" in rec
-        want, want2 = template(lambda: ops.conv1x1_split(x, A, K)), template(lambda: ops.conv1x1_split(x, A, K, sc, b, True))
+        want, want2 = template(x, A, K), template(x, A, K, sc, b, True)
         for _ in range(3):
             assert torch.equal(ops.conv1x1_split(x, A, K), want), (N, C, H, W, K)
             assert torch.equal(ops.conv1x1_split(x, A, K, sc, b, True), want2), (N, C, H, W, K)
         assert torch.equal(got, want)
         wide = torch.full((N, K + 8, H, W), 2.5, device=DEV)
         ops.conv1x1_split(x, A, K, None, b, False, out=wide[:, 4:4 + K])
-        assert torch.equal(wide[:, 4:4 + K], template(lambda: ops.conv1x1_split(x, A, K, None, b, False)))
+        assert torch.equal(wide[:, 4:4 + K], template(x, A, K, None, b, False))
         assert torch.all(wide[:, :4] == 2.5) and torch.all(wide[:, 4 + K:] == 2.5)
 
 
@@ -1256,26 +1242,42 @@ def ops_recorder(rec):
 
 
 def test_networks_agree_across_conv_arithmetic(vo):
-    """Flow and disparity at 480x640 (every 3x3 layer large enough for the split-bf16 kernel) with the
-    float32-matrix-instruction kernels only against the default split-bf16 products, and each against
-    the stock-operator restatement: both inside the 0.05 px budget by three orders of magnitude."""
-    from visual_odometry_amd.raft import layers
+    """Flow and disparity at 480x640 (every 3x3 layer large enough for the split kernels) under the three product
+    arithmetics -- float16 pieces (the default), bf16 pieces, float32 matrix instructions only -- against each
+    other and against the stock-operator restatement: all inside the 0.05 px budget by three orders of
+    magnitude.  The arithmetic is a field of each model: a second model in the same process keeps its own."""
     from visual_odometry_amd.raft.models import RAFTFlow, RAFTStereo, RAFTStereoConfig
     torch.manual_seed(12)
     flow, stereo = RAFTFlow().to(DEV).eval(), RAFTStereo(RAFTStereoConfig.realtime()).to(DEV).eval()
+    assert flow.conv_arithmetic == "f16x3" and stereo.conv_arithmetic == "f16x3"
     left, right = _images(1, 480, 640, seed=8)
-    try:
-        layers.conv_arithmetic("f32")
-        f0, d0 = flow(left[:1], left[1:2], iters=6)[1], stereo(left[:1], right[:1], iters=6)[1]
-    finally:
-        layers.conv_arithmetic("bf16x3")
-    f1, d1 = flow(left[:1], left[1:2], iters=6)[1], stereo(left[:1], right[:1], iters=6)[1]
-    assert not torch.equal(f0, f1)                                   # the switch did change the arithmetic
-    assert _epe(f1, f0) < 1e-3 and (d1 - d0).abs().mean().item() < 1e-3
+    out = {}
+    for kind in ("f32", "bf16x3", "f16x3"):
+        flow.conv_arithmetic = stereo.conv_arithmetic = kind
+        rec = {}
+        old = ops_recorder(rec)
+        try:
+            out[kind] = (flow(left[:1], left[1:2], iters=6)[1], stereo(left[:1], right[:1], iters=6)[1])
+        finally:
+            ops_recorder(old)
+        # the kernels that ran are the arithmetic's own
+        assert ("vo_conv3x3_winograd4" in rec) == (kind == "f32")
+        assert ("vo_conv3x3_bf16x3" in rec) == (kind != "f32")
+        assert ("vo_corr_volume_2d_presplit" in rec) == (kind == "bf16x3")
+        assert ("vo_corr_volume_2d" in rec) == (kind != "bf16x3")
+    with pytest.raises(ValueError):
+        flow.conv_arithmetic = "fp8"
+        flow(left[:1], left[1:2], iters=1)
+    flow.conv_arithmetic = "f16x3"
+    assert not torch.equal(out["f32"][0], out["bf16x3"][0]) and not torch.equal(out["f16x3"][0], out["bf16x3"][0])
     _, f_ref = raft_ref.raft_flow_forward(flow, left[:1], left[1:2], iters=6)
     _, d_ref = raft_ref.raft_stereo_forward(stereo, left[:1], right[:1], iters=6)
-    assert _epe(f1, f_ref) < 1e-3 and (d1 - d_ref).abs().mean().item() < 1e-3
-    assert _epe(f0, f_ref) < 1e-3 and (d0 - d_ref).abs().mean().item() < 1e-3
+    err = {}
+    for kind, (f, d) in out.items():
+        err[kind] = (_epe(f, f_ref), (d - d_ref).abs().mean().item())
+        assert err[kind][0] < 1e-3 and err[kind][1] < 1e-3, (kind, err[kind])
+        assert _epe(f, out["f32"][0]) < 1e-3 and (d - out["f32"][1]).abs().mean().item() < 1e-3
+    print("px error against the stock-operator restatement (flow EPE, disparity):", err)
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(1, 8, 5, 7, 64), (2, 16, 33, 21, 40), (2, 64, 60, 80, 126), (1, 24, 1, 1, 33),

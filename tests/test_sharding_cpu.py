@@ -96,6 +96,66 @@ def test_gather_poses_two_ranks_gloo(n_pairs):
             np.testing.assert_array_equal(compose_trajectory(z["T"], z["s"]), ref.compose_trajectory(T, skipped))
 
 
+def _long_worker(rank, world, n_pairs, port, out_dir):
+    import hashlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, skipped = _poses_fast(n_pairs, seed=7)
+    s, e = shard_pairs(n_pairs, rank, world)
+    Tg, sg = gather_poses(torch.from_numpy(T[s:e]), torch.from_numpy(skipped[s:e]), n_pairs)
+    G = compose_trajectory(Tg, sg)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), digest=np.frombuffer(hashlib.sha256(G.tobytes()).digest(), np.uint8),
+             last=G[-1], n=np.array([Tg.shape[0], int(sg.sum())]))
+    dist.destroy_process_group()
+
+
+def _poses_fast(n, seed):
+    """n small rigid motions (Rodrigues, vectorised) and 1 % skip flags."""
+    rng = np.random.default_rng(seed)
+    w = rng.normal(0, 0.01, (n, 3))
+    th = np.linalg.norm(w, axis=1)[:, None, None]
+    k = w / np.maximum(np.linalg.norm(w, axis=1, keepdims=True), 1e-30)
+    Kx = np.zeros((n, 3, 3))
+    Kx[:, 0, 1], Kx[:, 0, 2], Kx[:, 1, 0], Kx[:, 1, 2], Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+    T = np.tile(np.eye(4), (n, 1, 1))
+    T[:, :3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+    T[:, :3, 3] = rng.uniform(-0.05, 0.05, (n, 3))
+    return T, rng.random(n) < 0.01
+
+
+def test_long_sequence_gather_and_composition_two_ranks_gloo():
+    """The long-sequence configuration at size: 100 000 pose rows cut into two shards, all-gathered (1.7 MB of
+    float64 rows per rank) and composed on every rank -- bit for bit the unsharded composition
+    (test_camera_tracking.py:116,188-190,210)."""
+    import hashlib
+    n_pairs, world = 100_000, 2
+    port = 33500 + (os.getpid() % 2000)
+    T, skipped = _poses_fast(n_pairs, seed=7)
+    want = compose_trajectory(T, skipped)
+    digest = np.frombuffer(hashlib.sha256(want.tobytes()).digest(), np.uint8)
+    assert np.abs(want[-1][:3, :3] @ want[-1][:3, :3].T - np.eye(3)).max() < 1e-9      # still rigid after 99 k products
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_long_worker, args=(world, n_pairs, port, d), nprocs=world, join=True)
+        for r in range(world):
+            z = np.load(os.path.join(d, f"rank{r}.npz"))
+            np.testing.assert_array_equal(z["n"], [n_pairs, int(skipped.sum())])
+            np.testing.assert_array_equal(z["last"], want[-1])
+            np.testing.assert_array_equal(z["digest"], digest)
+
+
+def test_eight_rank_blocks_of_the_long_sequence_reassemble():
+    """The same 100 000 rows in the eight blocks an 8-GPU node would hold (12 500 each), reassembled in
+    rank order without a process group: the partition and the padding rule, not the collective."""
+    n_pairs, world = 100_000, 8
+    T, skipped = _poses_fast(n_pairs, seed=9)
+    blocks = [shard_pairs(n_pairs, r, world) for r in range(world)]
+    assert [e - s for s, e in blocks] == [12_500] * 8
+    Tg = np.concatenate([T[s:e] for s, e in blocks]); sg = np.concatenate([skipped[s:e] for s, e in blocks])
+    np.testing.assert_array_equal(compose_trajectory(Tg, sg), compose_trajectory(T, skipped))
+
+
 def _fake_frames(n_frames, seed=5):
     g = torch.Generator().manual_seed(seed)
     return (torch.randint(0, 255, (n_frames, 4, 6), dtype=torch.uint8, generator=g),

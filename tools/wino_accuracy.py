@@ -16,14 +16,18 @@ left, right = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
 def run():
     with torch.no_grad():
         return vo.flows(left), vo.disparity_solver.compute_disparity_gray_batch(left[1:], right[1:])
-layers.winograd_enabled(False)
-f0, d0 = run()
-f0b, d0b = run()
-layers.winograd_enabled(True)
+vo.set_conv_arithmetic("f32")
+with layers.arithmetic(hand_kernels=False):
+    f0, d0 = run()
+    f0b, d0b = run()
 print(f"MIOpen run to run: flow EPE {(f0b - f0).pow(2).sum(1).sqrt().mean().item():.2e} px, disparity {(d0b - d0).abs().mean().item():.2e} px")
 for tile in (2, 4, 0):
-    layers.winograd_tile(tile)
-    f, d = run()
+    with layers.arithmetic(winograd_tile=tile):
+        f, d = run()
     print(f"tile {tile}: flow EPE mean {(f - f0).pow(2).sum(1).sqrt().mean().item():.2e} max {(f - f0).abs().max().item():.2e} px; "
           f"disparity mean {(d - d0).abs().mean().item():.2e} max {(d - d0).abs().max().item():.2e} px")
-layers.winograd_tile(0)
+for kind in ("bf16x3", "f16x3"):
+    vo.set_conv_arithmetic(kind)
+    f, d = run()
+    print(f"{kind}: flow EPE mean {(f - f0).pow(2).sum(1).sqrt().mean().item():.2e} max {(f - f0).abs().max().item():.2e} px; "
+          f"disparity mean {(d - d0).abs().mean().item():.2e} max {(d - d0).abs().max().item():.2e} px")

@@ -13,6 +13,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libvo_hip.so")
 
 VO_OK, VO_ERR_INVALID_ARG, VO_ERR_LAUNCH, VO_ERR_UNSUPPORTED = 0, -1, -2, -3
+ABI_VERSION = 300           # the VO_HIP_VERSION of include/vo_hip.h that SIGNATURES below was written for
+VO_PIECES_BF16, VO_PIECES_F16 = 0, 1
 
 _P, _I, _L, _D, _F = c_void_p, c_int, c_int64, c_double, c_float
 
@@ -32,21 +34,21 @@ SIGNATURES = {
     "vo_conv3x3_winograd": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     "vo_winograd4_filter": [_P, _P, _I, _I, _P],
     "vo_conv3x3_winograd4": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
-    "vo_conv3x3_bf16x3_filter": [_P, _P, _I, _I, _P],
-    "vo_conv3x3_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
-    "vo_conv5_bf16x3_filter": [_P, _P, _I, _I, _P],
-    "vo_conv5_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "vo_conv3x3s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "vo_conv3x3s2_shortcut_bf16x3": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "vo_conv1x1_bf16x3_filter": [_P, _P, _I, _I, _P],
-    "vo_conv1x1_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "vo_conv1x1_pixel_major_bf16x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv3x3_bf16x3_filter": [_P, _P, _I, _I, _I, _I, _P],
+    "vo_conv3x3_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv5_bf16x3_filter": [_P, _P, _I, _I, _I, _I, _P],
+    "vo_conv5_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv3x3s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv3x3s2_shortcut_bf16x3": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv1x1_bf16x3_filter": [_P, _P, _I, _I, _I, _I, _P],
+    "vo_conv1x1_bf16x3": [_P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv1x1_pixel_major_bf16x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_split_rows_bf16x3": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "vo_conv1x1s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "vo_conv7x7_bf16x3_filter": [_P, _P, _I, _I, _P],
-    "vo_conv7x7_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "vo_gru_conv_zr_bf16x3": [_P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "vo_gru_conv_q_bf16x3": [_P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv1x1s2_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_conv7x7_bf16x3_filter": [_P, _P, _I, _I, _I, _I, _P],
+    "vo_conv7x7_bf16x3": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_gru_conv_zr_bf16x3": [_P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vo_gru_conv_q_bf16x3": [_P, _P, _P, _P, _P, _L, _P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_winograd1d_filter": [_P, _P, _I, _I, _P],
     "vo_conv5_winograd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vo_conv1x1_filter": [_P, _P, _I, _I, _P],
@@ -110,6 +112,12 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m visual_odometry_amd.build` "
             "(hipcc, gfx950). There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.vo_version.argtypes = []
+    lib.vo_version.restype = c_int
+    if lib.vo_version() != ABI_VERSION:
+        raise RuntimeError(
+            f"{LIB_PATH} reports version {lib.vo_version()}, this binding was written for {ABI_VERSION}: "
+            "rebuild it with `python -m visual_odometry_amd.build` (a stale library would take shifted arguments)")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -118,8 +126,6 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = c_int64
-    lib.vo_version.argtypes = []
-    lib.vo_version.restype = c_int
     lib.vo_last_error.argtypes = []
     lib.vo_last_error.restype = c_char_p
     _lib = lib

@@ -16,6 +16,6 @@ int vo_fail(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int vo_version(void) { return 0 * 10000 + 1 * 100 + 0; }
+extern "C" int vo_version(void) { return VO_HIP_VERSION; }
 
 extern "C" const char* vo_last_error(void) { return g_last_error; }

@@ -1,7 +1,7 @@
 // 7x7 padding-3 convolution (stride 1 or 2) of a ONE- or TWO-channel float32 input (the encoders' stems
 // on a gray frame, the motion encoders' first flow layer) with every float32 product assembled from
-// three bf16 matrix-core terms (xl*wh + xh*wl + xh*wh, float32 accumulation, 16 significant bits per
-// product), and optionally the plane sums an instance norm needs.
+// three 16-bit matrix-core terms (xl*wh + xh*wl + xh*wh, float32 accumulation; bf16 or float16 pieces,
+// see vo_pieces.h), and optionally the plane sums an instance norm needs.
 //
 // With so few input channels the layer is bound by the store of its 64+ output channels, so the
 // kernel is built around the output stream:
@@ -16,46 +16,36 @@
 // written as one 16-byte LDS entry per part; a lane's fragment for any filter column is then a single
 // aligned 16-byte read, lanes on consecutive entries (stride 2: even and odd columns stored apart).
 #include "vo_common.h"
+#include "vo_pieces.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KB = 64;                        // output channels per workgroup
 constexpr int SEG = 64;                       // output columns per segment
 constexpr int NT = 256;
 constexpr int A_STEP = 2 * 2 * 64 * 16;       // bytes of weights per k-step: [part][channel tile][lane][16]
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    f32x2 v = {a, b};
-    bf16x2 p = __builtin_convertvector(v, bf16x2);          // round to nearest even
-    return __builtin_bit_cast(unsigned, p);
-}
-
 // Weights (K,C,7,7) float32 -> high and low bf16 parts in A-operand order:
 //   Ag[kb][c*4 + j][part][mt][lane][r]:  k = kb*64 + mt*32 + (lane & 31),  s = 2j + (lane >> 5); r = 7 or s = 7: zero
+template <typename P>
 __global__ __launch_bounds__(256) void filter7_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ Ag, int K,
-                                                            int C, int Kpad) {
+                                                            int C, int Kpad, float wscale) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)Kpad * C * 64) return;
     const int r = (int)(idx & 7), s = (int)((idx >> 3) & 7), c = (int)((idx >> 6) % C), k = (int)((idx >> 6) / C);
     const float v = (k < K && r < 7 && s < 7) ? w[(((int64_t)k * C + c) * 7 + r) * 7 + s] : 0.0f;
-    const unsigned hi = pack_bf16(v, 0.0f) & 0xffffu;
-    const unsigned lo = pack_bf16(v - __uint_as_float(hi << 16), 0.0f) & 0xffffu;
+    unsigned hi, lo;
+    P::cut_weight(v, wscale, hi, lo);
     const int kb = k >> 6, mt = (k >> 5) & 1, lane = (s & 1) * 32 + (k & 31), j = s >> 1;
     const int64_t base = (((int64_t)kb * C + c) * 4 + j) * 4;                  // [part][mt]
     Ag[((base + 0 * 2 + mt) * 64 + lane) * 8 + r] = (unsigned short)hi;
     Ag[((base + 1 * 2 + mt) * 64 + lane) * 8 + r] = (unsigned short)lo;
 }
 
-struct Epi { const float* scale; const float* shift; int relu; double* stats; };
+struct Epi { const float* scale; const float* shift; int relu; double* stats; float unscale; };
 
 // S: stride, CIN: input channels (1 or 2).  (H, W): input size, (Ho, Wo): output size.
-template <int S, int CIN, bool STATS>
+template <typename P, int S, int CIN, bool STATS>
 __global__ __launch_bounds__(NT, 2) void conv7_split_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
                                                             float* __restrict__ y, Epi ep, int H, int W, int Ho, int Wo, int K,
                                                             int strips, int kblocks) {
@@ -127,10 +117,10 @@ __global__ __launch_bounds__(NT, 2) void conv7_split_kernel(const float* __restr
             u32x4 hi, lo;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const float a = raw[i][2 * jj], b = raw[i][2 * jj + 1];
-                const unsigned h = pack_bf16(a, b);
+                unsigned h, l;
+                P::cut(raw[i][2 * jj], raw[i][2 * jj + 1], h, l);
                 hi[jj] = h;
-                lo[jj] = pack_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+                lo[jj] = l;
             }
             *reinterpret_cast<u32x4*>(t_lds + e_lds[i]) = hi;
             *reinterpret_cast<u32x4*>(t_lds + T_PART + e_lds[i]) = lo;
@@ -165,28 +155,35 @@ __global__ __launch_bounds__(NT, 2) void conv7_split_kernel(const float* __restr
         for (int c = 0; c < CIN; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bf16x8 fa[2][2], fb[2][2];
+                u32x4 fa[2][2], fb[2][2];
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        fa[part][mt] = *reinterpret_cast<const bf16x8*>(a_base + (c * 4 + j) * A_STEP + (part * 2 + mt) * 1024);
+                        fa[part][mt] = *reinterpret_cast<const u32x4*>(a_base + (c * 4 + j) * A_STEP + (part * 2 + mt) * 1024);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         // input column of (pixel t*32 + nn, filter column 2j + lh), relative to the segment's first
                         const int pos = S == 1 ? (t * 32 + nn) + 2 * j + lh : lh * (PWE / 2) + (t * 32 + nn) + j;
-                        fb[part][t] = *reinterpret_cast<const bf16x8*>(t_lds + part * T_PART + ((c * 4 + wave) * PWE + pos) * 16);
+                        fb[part][t] = *reinterpret_cast<const u32x4*>(t_lds + part * T_PART + ((c * 4 + wave) * PWE + pos) * 16);
                     }
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][mt], fb[0][t], acc[mt][t], 0, 0, 0);
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mt], fb[1][t], acc[mt][t], 0, 0, 0);
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mt], fb[0][t], acc[mt][t], 0, 0, 0);
+                        acc[mt][t] = P::mfma(fa[1][mt], fb[0][t], acc[mt][t]);
+                        acc[mt][t] = P::mfma(P::for_low_input(fa[0][mt]), fb[1][t], acc[mt][t]);
+                        acc[mt][t] = P::mfma(fa[0][mt], fb[0][t], acc[mt][t]);
                     }
             }
+
+        if constexpr (P::F16) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[mt][t] *= ep.unscale;    // back to the weights' own scale (a power of two)
+        }
 
         // C/D layout of a 32x32 tile: pixel = lane & 31, channel row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
         // K is a multiple of 8, so a group of channel rows 8g..8g+7 is valid or not as a whole (wave-uniform);
@@ -265,31 +262,50 @@ __global__ __launch_bounds__(NT, 2) void conv7_split_kernel(const float* __restr
     }
 }
 
-template <int S, int CIN>
+template <typename P, int S, int CIN>
 void launch7(const float* x, const unsigned short* ag, float* y, const Epi& ep, int N, int H, int W, int Ho, int Wo, int K,
              hipStream_t st) {
     const int strips = (Ho + 3) / 4, kblocks = (K + KB - 1) / KB;
     const dim3 grid((unsigned)((int64_t)N * strips * kblocks));
-    if (ep.stats) conv7_split_kernel<S, CIN, true><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, H, W, Ho, Wo, K, strips, kblocks);
-    else conv7_split_kernel<S, CIN, false><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, H, W, Ho, Wo, K, strips, kblocks);
+    if (ep.stats) conv7_split_kernel<P, S, CIN, true><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, H, W, Ho, Wo, K, strips, kblocks);
+    else conv7_split_kernel<P, S, CIN, false><<<grid, dim3(NT), 0, st>>>(x, ag, y, ep, H, W, Ho, Wo, K, strips, kblocks);
+}
+
+template <typename P>
+void launch7_any(const float* x, const unsigned short* ag, float* y, const Epi& ep, int N, int C, int H, int W, int Ho, int Wo, int K,
+                 int stride, hipStream_t st) {
+    if (stride == 1 && C == 1) launch7<P, 1, 1>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
+    else if (stride == 1) launch7<P, 1, 2>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
+    else if (C == 1) launch7<P, 2, 1>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
+    else launch7<P, 2, 2>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
 }
 
 }  // namespace
 
-extern "C" int vo_conv7x7_bf16x3_filter(const float* weight, void* arranged, int K, int C, void* stream) {
+extern "C" int vo_conv7x7_bf16x3_filter(const float* weight, void* arranged, int K, int C, int pieces, int weight_exp, void* stream) {
     VO_REQUIRE(weight && arranged, "vo_conv7x7_bf16x3_filter: null pointer");
+    VO_REQUIRE(pieces == VO_PIECES_BF16 || pieces == VO_PIECES_F16, "vo_conv7x7_bf16x3_filter: pieces must be VO_PIECES_BF16 or VO_PIECES_F16");
+    VO_REQUIRE(weight_exp >= -100 && weight_exp <= 100 && (pieces == VO_PIECES_F16 || weight_exp == 0),
+               "vo_conv7x7_bf16x3_filter: weight_exp out of range (0 with bf16 pieces)");
     VO_REQUIRE(K > 0 && (C == 1 || C == 2), "vo_conv7x7_bf16x3_filter: bad sizes K=%d C=%d (one or two input channels)", K, C);
     const int Kpad = (K + KB - 1) / KB * KB;
     const int64_t n = (int64_t)Kpad * C * 64;
-    filter7_split_kernel<<<dim3((unsigned)vo_ceil_div(n, 256)), dim3(256), 0, vo_stream(stream)>>>(
-        weight, static_cast<unsigned short*>(arranged), K, C, Kpad);
+    if (pieces == VO_PIECES_F16)
+        filter7_split_kernel<PiecesF16><<<dim3((unsigned)vo_ceil_div(n, 256)), dim3(256), 0, vo_stream(stream)>>>(
+            weight, static_cast<unsigned short*>(arranged), K, C, Kpad, ldexpf(1.0f, weight_exp));
+    else
+        filter7_split_kernel<PiecesBf16><<<dim3((unsigned)vo_ceil_div(n, 256)), dim3(256), 0, vo_stream(stream)>>>(
+            weight, static_cast<unsigned short*>(arranged), K, C, Kpad, 1.0f);
     VO_CHECK_LAUNCH("vo_conv7x7_bf16x3_filter");
     return VO_OK;
 }
 
 extern "C" int vo_conv7x7_bf16x3(const float* x, const void* arranged, float* y, const float* scale, const float* shift, int relu,
-                                 double* stats, int N, int C, int H, int W, int K, int stride, void* stream) {
+                                 double* stats, int N, int C, int H, int W, int K, int stride, int pieces, int weight_exp, void* stream) {
     VO_REQUIRE(x && arranged && y, "vo_conv7x7_bf16x3: null pointer");
+    VO_REQUIRE(pieces == VO_PIECES_BF16 || pieces == VO_PIECES_F16, "vo_conv7x7_bf16x3: pieces must be VO_PIECES_BF16 or VO_PIECES_F16");
+    VO_REQUIRE(weight_exp >= -100 && weight_exp <= 100 && (pieces == VO_PIECES_F16 || weight_exp == 0),
+               "vo_conv7x7_bf16x3: weight_exp out of range (0 with bf16 pieces)");
     VO_REQUIRE(N > 0 && (C == 1 || C == 2) && H > 0 && W > 0 && K > 0, "vo_conv7x7_bf16x3: bad sizes (one or two input channels)");
     VO_REQUIRE(stride == 1 || stride == 2, "vo_conv7x7_bf16x3: stride must be 1 or 2");
     if (K % 8 != 0) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv7x7_bf16x3: K=%d is not a multiple of 8", K);
@@ -301,13 +317,11 @@ extern "C" int vo_conv7x7_bf16x3(const float* x, const void* arranged, float* y,
         return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv7x7_bf16x3: one image of the input exceeds 1 GiB or of the output 2 GiB");
     const int64_t blocks = (int64_t)N * ((Ho + 3) / 4) * ((K + KB - 1) / KB);
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_conv7x7_bf16x3: grid too large");
-    const Epi ep{scale, shift, relu, stats};
+    const Epi ep{scale, shift, relu, stats, pieces == VO_PIECES_F16 ? ldexpf(1.0f, -weight_exp) : 1.0f};
     const unsigned short* ag = static_cast<const unsigned short*>(arranged);
     hipStream_t st = vo_stream(stream);
-    if (stride == 1 && C == 1) launch7<1, 1>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
-    else if (stride == 1) launch7<1, 2>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
-    else if (C == 1) launch7<2, 1>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
-    else launch7<2, 2>(x, ag, y, ep, N, H, W, Ho, Wo, K, st);
+    if (pieces == VO_PIECES_F16) launch7_any<PiecesF16>(x, ag, y, ep, N, C, H, W, Ho, Wo, K, stride, st);
+    else launch7_any<PiecesBf16>(x, ag, y, ep, N, C, H, W, Ho, Wo, K, stride, st);
     VO_CHECK_LAUNCH("vo_conv7x7_bf16x3");
     return VO_OK;
 }

@@ -227,6 +227,36 @@ def avg_pool3x3s2(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Ten
     return out
 
 
+# ------------------------------------------------------------ split arithmetic
+# The split convolutions cut every float32 operand into two 16-bit pieces; ``pieces`` names the format:
+# "bf16" (16 significant bits, float32's exponent range) or "f16" (22 significant bits; float16's exponent
+# range is met with exact powers of two -- see include/vo_hip.h, VO_PIECES_F16).  An arranged weight tensor
+# carries its format and its power of two as attributes, so a convolution cannot be handed the wrong ones.
+PIECES = {"bf16": _lib.VO_PIECES_BF16, "f16": _lib.VO_PIECES_F16}
+
+
+def _weight_exp(weight: torch.Tensor, pieces: str) -> int:
+    """The e with max|w| * 2^e in [2^13, 2^14) for float16 pieces (0 for bf16, and for an all-zero weight)."""
+    if pieces != "f16":
+        return 0
+    m = float(weight.detach().abs().max())
+    if not np.isfinite(m):
+        raise ValueError("weights must be finite")
+    if m == 0.0:
+        return 0
+    return int(13 - np.floor(np.log2(m)))
+
+
+def _tag(arranged: torch.Tensor, pieces: str, wexp: int) -> torch.Tensor:
+    arranged.vo_pieces, arranged.vo_wexp = pieces, wexp
+    return arranged
+
+
+def _pieces_of(arranged: torch.Tensor):
+    """(pieces code, weight_exp) of an arranged weight tensor (bf16 pieces when it carries no tag)."""
+    return PIECES[getattr(arranged, "vo_pieces", "bf16")], int(getattr(arranged, "vo_wexp", 0))
+
+
 def winograd_filter(weight: torch.Tensor, tile: int = 2) -> torch.Tensor:
     """(K,C,3,3) float32 weight -> the transformed filter conv3x3_winograd consumes.
     ``tile`` 2: F(2x2,3x3), 16 positions; 4: F(4x4,3x3), 36 positions (fewer multiplies,
@@ -245,18 +275,20 @@ def winograd_filter(weight: torch.Tensor, tile: int = 2) -> torch.Tensor:
     return out
 
 
-def conv3x3_split_filter(weight: torch.Tensor) -> torch.Tensor:
-    """(K,C,3,3) float32 weight -> the bf16 high/low parts in operand order that conv3x3_winograd
-    hands to the split-bf16 direct kernel (a float32 tensor used as raw storage, ceil(K/64)*64*C*9
-    elements).  C must be a multiple of 16."""
+def conv3x3_split_filter(weight: torch.Tensor, pieces: str = "bf16") -> torch.Tensor:
+    """(K,C,3,3) float32 weight -> its high/low 16-bit parts in operand order that conv3x3_winograd
+    hands to the split direct kernel (a float32 tensor used as raw storage, ceil(K/64)*64*C*9
+    elements, tagged with ``pieces`` and its power of two).  C must be a multiple of 16."""
     if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
         raise ValueError("weight must be (K,C,3,3)")
     K, C = weight.shape[:2]
     if C % 16:
         raise ValueError("the split-bf16 path needs a multiple of 16 input channels")
     out = torch.empty(((K + 63) // 64 * 64 * C * 9,), device=weight.device, dtype=torch.float32)
-    _call("vo_conv3x3_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
-    return out
+    wexp = _weight_exp(weight, pieces)
+    _call("vo_conv3x3_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C,
+          PIECES[pieces], wexp, _stream())
+    return _tag(out, pieces, wexp)
 
 
 def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: torch.Tensor | None = None,
@@ -305,7 +337,8 @@ def conv3x3_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, scale: 
     _call(name, _dev(x, "x", torch.float32), _dev(transformed, "filter", torch.float32), py, sy,
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
           _opt(skip, "skip", torch.float32), _opt(stats, "stats", torch.float64),
-          _opt(in_stats, "in_stats", torch.float64), float(in_eps), N, C, H, W, K, _stream(),
+          _opt(in_stats, "in_stats", torch.float64), float(in_eps), N, C, H, W, K,
+          *(_pieces_of(transformed) if tile == 1 else ()), _stream(),
           nbytes=4 * (x.numel() + out.numel() * (1 + (skip is not None))),
           flops=2 * positions * C * K * N * ((H + tile - 1) // tile) * ((W + tile - 1) // tile))   # multiply-adds the kernel issues
                                                                                                   # (Winograd domain / three bf16 terms)
@@ -337,7 +370,7 @@ def conv5_winograd(x: torch.Tensor, transformed: torch.Tensor, K: int, vertical:
     return out
 
 
-def conv5_split_filter(weight: torch.Tensor) -> torch.Tensor:
+def conv5_split_filter(weight: torch.Tensor, pieces: str = "bf16") -> torch.Tensor:
     """(K,C,1,5) or (K,C,5,1) float32 weight -> bf16 high/low parts in operand order for conv5_split
     (a float32 tensor used as raw storage).  C must be a multiple of 16."""
     if weight.dim() != 4 or tuple(weight.shape[2:]) not in ((1, 5), (5, 1)):
@@ -346,8 +379,10 @@ def conv5_split_filter(weight: torch.Tensor) -> torch.Tensor:
     if C % 16:
         raise ValueError("the split-bf16 path needs a multiple of 16 input channels")
     out = torch.empty(((K + 63) // 64 * 64 * C * 5,), device=weight.device, dtype=torch.float32)
-    _call("vo_conv5_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C, _stream())
-    return out
+    wexp = _weight_exp(weight, pieces)
+    _call("vo_conv5_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C,
+          PIECES[pieces], wexp, _stream())
+    return _tag(out, pieces, wexp)
 
 
 def conv5_split(x: torch.Tensor, arranged: torch.Tensor, K: int, vertical: bool, scale: torch.Tensor | None = None,
@@ -369,7 +404,7 @@ def conv5_split(x: torch.Tensor, arranged: torch.Tensor, K: int, vertical: bool,
     py, sy = _slice(out, "out")
     _call("vo_conv5_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), py, sy,
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K,
-          int(bool(vertical)), _stream(), nbytes=4 * (x.numel() + out.numel()), flops=2 * 15 * N * K * C * H * W)
+          int(bool(vertical)), *_pieces_of(arranged), _stream(), nbytes=4 * (x.numel() + out.numel()), flops=2 * 15 * N * K * C * H * W)
     return out
 
 
@@ -392,12 +427,12 @@ def conv3x3s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torc
     out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
     _call("vo_conv3x3s2_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
-          _opt(stats, "stats", torch.float64), N, C, H, W, K, _stream(),
+          _opt(stats, "stats", torch.float64), N, C, H, W, K, *_pieces_of(arranged), _stream(),
           nbytes=4 * (x.numel() + out.numel()), flops=2 * 27 * N * K * C * Ho * Wo)
     return out
 
 
-def conv1x1_split_filter(weight: torch.Tensor) -> torch.Tensor:
+def conv1x1_split_filter(weight: torch.Tensor, pieces: str = "bf16") -> torch.Tensor:
     """(K,C,1,1) or (K,C) float32 weight, C a multiple of 16 -> the bf16 high/low parts in operand order
     that conv1x1s2_split consumes (a float32 tensor used as raw storage, ceil(K/64)*64*C elements)."""
     if weight.dim() not in (2, 4) or (weight.dim() == 4 and tuple(weight.shape[2:]) != (1, 1)):
@@ -406,13 +441,15 @@ def conv1x1_split_filter(weight: torch.Tensor) -> torch.Tensor:
     if C % 16:
         raise ValueError("the split-bf16 path needs a multiple of 16 input channels")
     out = torch.empty(((K + 63) // 64 * 64 * C,), device=weight.device, dtype=torch.float32)
+    wexp = _weight_exp(weight, pieces)
     _call("vo_conv1x1_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C,
-          _stream())
-    return out
+          PIECES[pieces], wexp, _stream())
+    return _tag(out, pieces, wexp)
 
 
 def conv1x1_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
-                  shift: torch.Tensor | None = None, relu: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+                  shift: torch.Tensor | None = None, relu: bool = False, out: torch.Tensor | None = None,
+                  use_template: bool = False) -> torch.Tensor:
     """conv2d(x, weight(K,C,1,1)) on the split-bf16 direct kernel (weights from conv1x1_split_filter), optional
     epilogue v*scale[k] + shift[k], ReLU; ``out``: a (N,K,H,W) channel slice that receives the result."""
     N, C, H, W = x.shape
@@ -429,7 +466,8 @@ def conv1x1_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.
         raise ValueError("out must be a float32 (N,K,H,W) tensor or channel slice")
     py, sy = _slice(out, "out")
     _call("vo_conv1x1_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), py, sy,
-          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K,
+          *_pieces_of(arranged), int(bool(use_template)), _stream(),
           nbytes=4 * (x.numel() + out.numel()), flops=2 * 3 * N * K * C * H * W)
     return out
 
@@ -448,11 +486,21 @@ def conv1x1_pixel_major_split(x: torch.Tensor, arranged: torch.Tensor, K: int, s
         if t is not None and t.numel() != K:
             raise ValueError(f"{name} must have one entry per output channel")
     out = torch.empty((N, H, W, K), device=x.device, dtype=torch.float32)
+    if split_rows and _pieces_of(arranged)[0] != PIECES["bf16"]:
+        raise ValueError("rows split beforehand are bf16 pieces: the weights must be arranged with pieces='bf16'")
     _call("vo_conv1x1_split_rows_bf16x3" if split_rows else "vo_conv1x1_pixel_major_bf16x3", _dev(x, "x", torch.float32),
           _dev(arranged, "weights", torch.float32), out.data_ptr(),
-          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K, _stream(),
+          _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), N, C, H, W, K,
+          *(() if split_rows else _pieces_of(arranged)), _stream(),
           nbytes=4 * (x.numel() + out.numel()), flops=2 * 3 * N * K * C * H * W)
     return out
+
+
+def _both_pieces(a: torch.Tensor, b: torch.Tensor):
+    (pa, ea), (pb, eb) = _pieces_of(a), _pieces_of(b)
+    if pa != pb:
+        raise ValueError("the two weight tensors were arranged for different piece formats")
+    return pa, ea, eb
 
 
 def conv3x3s2_shortcut_split(x: torch.Tensor, arranged: torch.Tensor, arranged1x1: torch.Tensor, K: int,
@@ -482,7 +530,8 @@ def conv3x3s2_shortcut_split(x: torch.Tensor, arranged: torch.Tensor, arranged1x
           _dev(arranged1x1, "shortcut weights", torch.float32), y.data_ptr(), y2.data_ptr(),
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu), _opt(stats, "stats", torch.float64),
           _opt(scale2, "scale2", torch.float32), _opt(shift2, "shift2", torch.float32), int(relu2), _opt(stats2, "stats2", torch.float64),
-          N, C, H, W, K, _stream(), nbytes=4 * (x.numel() + 2 * y.numel()), flops=2 * 3 * N * K * C * Ho * Wo * 10)
+          N, C, H, W, K, *_both_pieces(arranged, arranged1x1), _stream(),
+          nbytes=4 * (x.numel() + 2 * y.numel()), flops=2 * 3 * N * K * C * Ho * Wo * 10)
     return y, y2
 
 
@@ -505,21 +554,22 @@ def conv1x1s2_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torc
     out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
     _call("vo_conv1x1s2_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
-          _opt(stats, "stats", torch.float64), N, C, H, W, K, _stream(),
+          _opt(stats, "stats", torch.float64), N, C, H, W, K, *_pieces_of(arranged), _stream(),
           nbytes=4 * (x.numel() // 2 + out.numel()), flops=2 * 3 * N * K * C * Ho * Wo)
     return out
 
 
-def conv7x7_split_filter(weight: torch.Tensor) -> torch.Tensor:
+def conv7x7_split_filter(weight: torch.Tensor, pieces: str = "bf16") -> torch.Tensor:
     """(K,C,7,7) float32 weight, C = 1 or 2 -> the bf16 high/low parts in operand order that conv7x7_split
     consumes (a float32 tensor used as raw storage, ceil(K/64)*64*C*64 elements)."""
     if weight.dim() != 4 or tuple(weight.shape[2:]) != (7, 7) or weight.shape[1] not in (1, 2):
         raise ValueError("weight must be (K,C,7,7) with one or two input channels")
     K, C = weight.shape[:2]
     out = torch.empty(((K + 63) // 64 * 64 * C * 64,), device=weight.device, dtype=torch.float32)
+    wexp = _weight_exp(weight, pieces)
     _call("vo_conv7x7_bf16x3_filter", _dev(weight.detach().contiguous(), "weight", torch.float32), out.data_ptr(), K, C,
-          _stream())
-    return out
+          PIECES[pieces], wexp, _stream())
+    return _tag(out, pieces, wexp)
 
 
 def conv7x7_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.Tensor | None = None,
@@ -542,7 +592,7 @@ def conv7x7_split(x: torch.Tensor, arranged: torch.Tensor, K: int, scale: torch.
     out = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32)
     _call("vo_conv7x7_bf16x3", _dev(x, "x", torch.float32), _dev(arranged, "weights", torch.float32), out.data_ptr(),
           _opt(scale, "scale", torch.float32), _opt(shift, "shift", torch.float32), int(relu),
-          _opt(stats, "stats", torch.float64), N, C, H, W, K, stride, _stream(),
+          _opt(stats, "stats", torch.float64), N, C, H, W, K, stride, *_pieces_of(arranged), _stream(),
           nbytes=4 * (x.numel() + out.numel()), flops=2 * 3 * N * K * C * 64 * Ho * Wo)
     return out
 
@@ -733,14 +783,14 @@ def gru_update(q: torch.Tensor, bias_q, cq, z: torch.Tensor, h: torch.Tensor, h_
 _GRU_SHAPES = {(3, 3): 0, (1, 5): 1, (5, 1): 2}
 
 
-def gru_split_filter(weight: torch.Tensor) -> torch.Tensor:
-    """(K,Cin,kh,kw) float32 GRU gate weights with (kh,kw) in 3x3 / 1x5 / 5x1 -> split-bf16 operands for
+def gru_split_filter(weight: torch.Tensor, pieces: str = "bf16") -> torch.Tensor:
+    """(K,Cin,kh,kw) float32 GRU gate weights with (kh,kw) in 3x3 / 1x5 / 5x1 -> split operands for
     gru_conv_zr / gru_conv_q."""
     ks = tuple(weight.shape[2:])
     if ks == (3, 3):
-        return conv3x3_split_filter(weight)
+        return conv3x3_split_filter(weight, pieces)
     if ks in ((1, 5), (5, 1)):
-        return conv5_split_filter(weight)
+        return conv5_split_filter(weight, pieces)
     raise ValueError("GRU gate convolutions are 3x3, 1x5 or 5x1")
 
 
@@ -761,7 +811,7 @@ def gru_conv_zr(buf: torch.Tensor, arranged: torch.Tensor, bias, cz, cr, h: torc
     pcz, scz = _slice(cz, "cz", buf); pcr, scr = _slice(cr, "cr", buf); ph, sh = _slice(h, "h", buf)
     _call("vo_gru_conv_zr_bf16x3", _dev(buf, "buf", torch.float32), _dev(arranged, "weights", torch.float32),
           _opt(bias, "bias", torch.float32), pcz, scz, pcr, scr, ph, sh, z.data_ptr(), rh.data_ptr(), B, Cin, H, W, C, shape,
-          _stream(), nbytes=4 * (buf.numel() + 3 * z.numel() + z.numel() * ((cz is not None) + (cr is not None))),
+          *_pieces_of(arranged), _stream(), nbytes=4 * (buf.numel() + 3 * z.numel() + z.numel() * ((cz is not None) + (cr is not None))),
           flops=2 * 3 * taps * B * 2 * C * Cin * H * W)
     return z, rh
 
@@ -783,7 +833,7 @@ def gru_conv_q(buf: torch.Tensor, rh: torch.Tensor, arranged: torch.Tensor, bias
     pcq, scq = _slice(cq, "cq", buf); ph, sh = _slice(h, "h", buf); pc, sc = _slice(h_copy, "h_copy", buf)
     _call("vo_gru_conv_q_bf16x3", _dev(buf, "buf", torch.float32), _dev(rh, "rh", torch.float32),
           _dev(arranged, "weights", torch.float32), _opt(bias, "bias", torch.float32), pcq, scq, _dev(z, "z", torch.float32),
-          ph, sh, h_out.data_ptr(), pc, sc, B, Cin, H, W, C, shape, _stream(),
+          ph, sh, h_out.data_ptr(), pc, sc, B, Cin, H, W, C, shape, *_pieces_of(arranged), _stream(),
           nbytes=4 * (buf.numel() + z.numel() * (3 + (cq is not None) + (h_copy is not None))),
           flops=2 * 3 * taps * B * C * Cin * H * W)
     return h_out

@@ -47,6 +47,10 @@ class VOConfig:
     ransac_iterations: int = 1000
     ransac_seed: int = 0
     mixed_precision: bool = False         # the models' switch; the reference passes False (flow_map_RAFT.py:38)
+    # how both networks form their heavy float32 products (raft.layers.Arithmetic.kind): "f16x3" = three float16
+    # matrix-core terms, the float32 instruction's error; "bf16x3" = three bf16 terms, 16 significant bits, about
+    # 5 % faster; "f32" = float32 matrix instructions only
+    conv_arithmetic: str = "f16x3"
 
 
 class _Rig:
@@ -67,9 +71,9 @@ class VisualOdometry:
         # (the reference rectifies inside each solver call, flow_map_RAFT.py:64-66, stereo_disparity_RAFT.py:74-75)
         self.rectification = rectification
         self.flow_solver = HipOpticalFlowRAFT(flow_checkpoint, None, cfg.iters, seed=seed,
-                                              mixed_precision=cfg.mixed_precision)
+                                              mixed_precision=cfg.mixed_precision, conv_arithmetic=cfg.conv_arithmetic)
         self.disparity_solver = HipDisparityRAFT(stereo_checkpoint, None, cfg.iters, config=cfg.stereo, seed=seed + 1,
-                                                 mixed_precision=cfg.mixed_precision)
+                                                 mixed_precision=cfg.mixed_precision, conv_arithmetic=cfg.conv_arithmetic)
         self.device = self.flow_solver.device
         self._fxB = focal_length_px * baseline
         self._f64 = isinstance(self._fxB, np.float64)
@@ -86,6 +90,15 @@ class VisualOdometry:
         self.keypoints = self.pts_src.get_keypoints_device(cfg.max_keypoints)
         self._cam = cam
         self._pose_ws = None
+
+    def set_conv_arithmetic(self, kind: str) -> None:
+        """Switch both networks of THIS pipeline to another product arithmetic (see VOConfig.conv_arithmetic)."""
+        from .raft.layers import CONV_ARITHMETICS
+        if kind not in CONV_ARITHMETICS:
+            raise ValueError(f"conv_arithmetic must be one of {CONV_ARITHMETICS}")
+        self.cfg.conv_arithmetic = kind
+        self.flow_solver.model.conv_arithmetic = kind
+        self.disparity_solver.model.conv_arithmetic = kind
 
     # -- stages ------------------------------------------------------------
     def depth_maps(self, left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:

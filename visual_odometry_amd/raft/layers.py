@@ -1,16 +1,24 @@
-"""Convolutional encoders of RAFT and RAFT-Stereo (PyTorch-ROCm / MIOpen).
+"""Convolutional encoders of RAFT and RAFT-Stereo.
 
-These stay ordinary ``nn.Module`` stacks; only the correlation / lookup /
-upsampling operators around them are hand-written HIP.  Sub-module names follow
-the published RAFT / RAFT-Stereo models (``conv1``, ``norm1``, ``layer1``..,
-``conv2``, ``outputs08``..) so that a state dict trained with those models,
-``module.`` prefix stripped, loads unchanged; the reference builds them with
-``RAFT(args)`` / ``RAFTStereo(args)`` at flow/flow_map_RAFT.py:42 and
-stereo/stereo_disparity_RAFT.py:46.
+The encoders are ``nn.Module`` trees that hold the parameters under the published models' names
+(``conv1``, ``norm1``, ``layer1``.., ``conv2``, ``outputs08``..), so that a state dict trained with those
+models, ``module.`` prefix stripped, loads unchanged; the reference builds them with ``RAFT(args)`` /
+``RAFTStereo(args)`` at flow/flow_map_RAFT.py:42 and stereo/stereo_disparity_RAFT.py:46.  Inside a
+product forward pass (``fused_passes()``) their arithmetic does NOT go to the framework's operators: every
+convolution of the float32 path is dispatched to a hand-written matrix-core kernel of ``ops`` (3x3, 1x5 /
+5x1, stride-2, 7x7 and 1x1 kernels with bias / folded batch norm / ReLU / residual join in their stores),
+instance norms are applied by the next kernel that reads the tensor, and the remaining passes are fused
+in-place HIP kernels.  With ``fused_passes()`` off the same modules run the stock PyTorch operators.
+
+Which kernels a forward pass uses is decided by the ``Arithmetic`` in force (``arithmetic(...)``), a
+context-local value that each model sets from its own ``conv_arithmetic`` field for the duration of its
+forward pass -- two pipelines in one process cannot change each other's arithmetic.
 """
 from __future__ import annotations
 
 import contextlib
+import contextvars
+import dataclasses
 
 import torch
 import torch.nn as nn
@@ -18,24 +26,79 @@ import torch.nn.functional as F
 
 from .. import ops
 
-# While this is on (the product's forward passes switch it on), norm -> ReLU and the
-# residual joins run as fused in-place HIP passes; off, the modules execute the
-# stock PyTorch operators (what the oracle runs).
-_FUSED = False
+CONV_ARITHMETICS = ("f16x3", "bf16x3", "f32")
+
+
+@dataclasses.dataclass(frozen=True)
+class Arithmetic:
+    """How a forward pass computes.
+      kind           how the heavy float32 products (3x3, 1x5 / 5x1, stride-2, many-channel 1x1 and 7x7 convolutions,
+                     GRU gate convolutions, correlation volumes) are formed:
+                       "f16x3"   three float16 matrix-core terms per product, x*w ~ xl*wh + xh*wl + xh*wh with both
+                                 operands cut into two float16 pieces: 22 significant bits per operand, float32
+                                 accumulation; the error of a layer is that of the float32 matrix instruction.  The
+                                 correlation volumes run on the float32 matrix instruction itself.
+                       "bf16x3"  the same with bf16 pieces: 16 significant bits per operand, largest error 4-6e-6 of a
+                                 layer's largest output; correlation volumes included.
+                       "f32"     float32 matrix instructions only (Winograd kernels for 3x3 and 1x5 / 5x1; the
+                                 F(4x4,3x3) form's rounding error is 1e-5 of the largest output).
+      fused          norm -> ReLU, residual joins and GRU gates as fused HIP passes and every convolution on the
+                     hand-written kernels (the product's forward passes switch it on); off: stock PyTorch operators.
+      hand_kernels   off: the convolutions themselves go to the framework (a switch for comparisons).
+      winograd_tile  0: F(2x2,3x3) or F(4x4,3x3) per layer shape in the "f32" path; 2 or 4 forces one."""
+    kind: str = "f16x3"
+    fused: bool = False
+    hand_kernels: bool = True
+    winograd_tile: int = 0
+
+
+_CURRENT = contextvars.ContextVar("vo_conv_arithmetic", default=Arithmetic())
+
+
+def current() -> Arithmetic:
+    return _CURRENT.get()
 
 
 @contextlib.contextmanager
-def fused_passes(on: bool = True):
-    global _FUSED
-    old, _FUSED = _FUSED, on
+def arithmetic(kind=None, *, fused=None, hand_kernels=None, winograd_tile=None):
+    """Put an Arithmetic in force for the enclosed calls (of this thread / context); fields left at None keep
+    the value of the enclosing scope."""
+    changes = {k: v for k, v in dict(kind=kind, fused=fused, hand_kernels=hand_kernels, winograd_tile=winograd_tile).items()
+               if v is not None}
+    if "kind" in changes and changes["kind"] not in CONV_ARITHMETICS:
+        raise ValueError(f"conv arithmetic must be one of {CONV_ARITHMETICS}")
+    if "winograd_tile" in changes and changes["winograd_tile"] not in (0, 2, 4):
+        raise ValueError("winograd_tile must be 0, 2 or 4")
+    token = _CURRENT.set(dataclasses.replace(_CURRENT.get(), **changes))
     try:
         yield
     finally:
-        _FUSED = old
+        _CURRENT.reset(token)
+
+
+def fused_passes(on: bool = True):
+    """The product's forward passes: fused HIP passes and hand-written convolution kernels on."""
+    return arithmetic(fused=bool(on))
 
 
 def fused_on() -> bool:
-    return _FUSED and not torch.is_autocast_enabled()
+    return _CURRENT.get().fused and not torch.is_autocast_enabled()
+
+
+def split_on() -> bool:
+    """True when the heavy float32 products are assembled from three 16-bit matrix-core terms."""
+    return _CURRENT.get().kind in ("f16x3", "bf16x3")
+
+
+def split_pieces() -> str:
+    """The piece format of the split kernels in force: "f16" or "bf16"."""
+    return "f16" if _CURRENT.get().kind == "f16x3" else "bf16"
+
+
+def bf16_pieces_on() -> bool:
+    """True under "bf16x3": the kernels that exist for bf16 pieces only (correlation volumes, rows split by
+    their producer, the weights-in-LDS 1x1 kernel) apply."""
+    return _CURRENT.get().kind == "bf16x3"
 
 
 _ACT_DTYPES = (torch.float32, torch.float16)
@@ -121,42 +184,23 @@ def conv_pixel_major(x: torch.Tensor, conv: nn.Conv2d, split_rows: bool = False)
     return ops.split_feature_rows(y, 32) if split_rows else y
 
 
-_WINOGRAD = True            # float32 3x3 stride-1 convolutions on the hand-written Winograd/MFMA kernels
-_WINOGRAD_TILE = 0          # 0: pick F(2x2,3x3) or F(4x4,3x3) per layer shape; 2 or 4: force one
-_SPLIT_BF16 = True          # 3x3 layers on the split-bf16 direct kernel where it applies (see conv_arithmetic)
+def _hand() -> bool:
+    return _CURRENT.get().hand_kernels
 
 
-def split_bf16_on() -> bool:
-    """True when the heavy float32 products (convolutions, correlation volume) are assembled from three
-    bf16 matrix-core terms (see conv_arithmetic)."""
-    return _SPLIT_BF16
-
-
-def conv_arithmetic(kind: str) -> None:
-    """How the float32 convolutions and the correlation volume form their products:
-      "bf16x3" (default)  every float32 product from bf16 pieces, x*w ~ xl*wh + xh*wl + xh*wh, on the
-                          bf16 matrix cores with float32 accumulation (16 significant bits per product,
-                          largest error 4-6e-6 of a layer's largest output);
-      "f32"               float32 matrix instructions only (the Winograd kernels; the F(4x4,3x3) form's
-                          rounding error is 1e-5 of the largest output)."""
-    global _SPLIT_BF16
-    if kind not in ("bf16x3", "f32"):
-        raise ValueError("conv_arithmetic must be 'bf16x3' or 'f32'")
-    _SPLIT_BF16 = kind == "bf16x3"
-
-
-def winograd_enabled(on: bool) -> None:
-    """Switch the hand-written 3x3 kernels on or off (off: every convolution goes to MIOpen)."""
-    global _WINOGRAD
-    _WINOGRAD = bool(on)
-
-
-def winograd_tile(tile: int) -> None:
-    """Force the output tile of the Winograd kernels (2 or 4), or 0 for the per-shape choice."""
-    global _WINOGRAD_TILE
-    if tile not in (0, 2, 4):
-        raise ValueError("tile must be 0, 2 or 4")
-    _WINOGRAD_TILE = tile
+def _split_cached(weight: torch.Tensor, attr: str, make):
+    """The split operands of ``weight`` for the piece format in force, cached on the weight tensor per
+    format; rebuilt when the weight changes or moves."""
+    pieces = split_pieces()
+    key = (weight._version, weight.data_ptr())
+    table = getattr(weight, attr, None)
+    if table is None or table[0] != key:
+        table = (key, {})
+        setattr(weight, attr, table)
+    A = table[1].get(pieces)
+    if A is None:
+        A = table[1][pieces] = make(weight, pieces)
+    return A
 
 
 def _winograd_tile_for(H: int, W: int, C: int = 0) -> int:
@@ -165,12 +209,12 @@ def _winograd_tile_for(H: int, W: int, C: int = 0) -> int:
     blocks (whichever covers the map with less padding) instead of 16x16: take it unless the padding
     of small maps eats the gain.  The split-bf16 kernel does a pixel in about 1/1.3 of F(4x4,3x3)'s
     time on 16x32-pixel blocks; it needs input channels in multiples of 16 and an even width."""
-    if _WINOGRAD_TILE:
-        return _WINOGRAD_TILE
+    if _CURRENT.get().winograd_tile:
+        return _CURRENT.get().winograd_tile
     up = lambda v, m: (v + m - 1) // m * m
     covered4 = min(up(H, 16) * up(W, 32), up(H, 32) * up(W, 16))
     best = (4, covered4) if covered4 < 1.55 * up(H, 16) * up(W, 16) else (2, 1.55 * up(H, 16) * up(W, 16))
-    if _SPLIT_BF16 and C % 16 == 0 and C > 0 and W % 2 == 0 and min(up(H, 16) * up(W, 32), up(H, 32) * up(W, 16)) < 1.3 * best[1]:
+    if split_on() and C % 16 == 0 and C > 0 and W % 2 == 0 and min(up(H, 16) * up(W, 32), up(H, 32) * up(W, 16)) < 1.3 * best[1]:
         return 1
     return best[0]
 
@@ -179,7 +223,7 @@ def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
     """The cached transformed filter when this convolution can run on a Winograd matrix-core
     kernel (3x3 / stride 1 / padding 1, float32, >= 32 output channels, input channels a
     multiple of 8), else None."""
-    if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+    if not (_hand() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] % 8 == 0 and weight.shape[0] >= 32
             and weight.shape[1] == x.shape[1]):
@@ -187,6 +231,8 @@ def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
     # the transformed filters ride on the weight tensor object itself (an address-keyed
     # table would hand a new model the filters of a freed one), one per kernel variant
     tile = _winograd_tile_for(x.shape[2], x.shape[3], x.shape[1])
+    if tile == 1:
+        return _split_cached(weight, "_vo_conv3x3_split", lambda w, pieces: ops.conv3x3_split_filter(w.contiguous(), pieces))
     key = (weight._version, weight.data_ptr())
     table = getattr(weight, "_vo_winograd", None)
     if table is None or table[0] != key:
@@ -194,15 +240,14 @@ def _winograd_filter_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
         weight._vo_winograd = table
     U = table[1].get(tile)
     if U is None:
-        U = table[1][tile] = (ops.conv3x3_split_filter(weight.contiguous()) if tile == 1
-                              else ops.winograd_filter(weight.contiguous(), tile))
+        U = table[1][tile] = ops.winograd_filter(weight.contiguous(), tile)
     return U
 
 
 def _conv1x1_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached arranged weights when this convolution can run on the streaming 1x1 matrix-core
     kernel (1x1 / stride 1 / no padding, float32, contiguous input), else None."""
-    if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+    if not (_hand() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
             and tuple(weight.shape[2:]) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
             and (x.shape[1] + 8) * x.shape[2] * x.shape[3] * 4 < 2 ** 31):
@@ -219,24 +264,19 @@ def _conv1x1_split_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, pa
     """The cached split-bf16 weights when this 1x1 convolution has enough channels on both sides for the matrix
     instruction, not memory, to bound the float32 streaming kernel (>= 64 in, >= 64 out, input channels a
     multiple of 16, even width), else None."""
-    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+    if not (_hand() and split_on() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
             and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (1, 1) and tuple(stride) == (1, 1)
             and tuple(padding) == (0, 0) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
             and x.shape[1] % 16 == 0 and x.shape[1] >= 64 and weight.shape[0] >= 64 and x.shape[3] % 2 == 0
             and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1 and weight.shape[0] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
         return None
-    key = (weight._version, weight.data_ptr())
-    cached = getattr(weight, "_vo_conv1x1_split", None)
-    if cached is None or cached[0] != key:
-        cached = (key, ops.conv1x1_split_filter(weight))
-        weight._vo_conv1x1_split = cached
-    return cached[1]
+    return _split_cached(weight, "_vo_conv1x1_split", ops.conv1x1_split_filter)
 
 
 def _conv7x7_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached arranged weights when this convolution can run on the streaming 7x7 matrix-core
     kernel (7x7 / stride 1 or 2 / padding 3, at most 8 input channels, float32), else None."""
-    if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+    if not (_hand() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
             and tuple(weight.shape[2:]) == (7, 7) and tuple(stride) in ((1, 1), (2, 2)) and tuple(padding) == (3, 3)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] <= 8
             and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
@@ -252,24 +292,19 @@ def _conv7x7_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding,
 def _conv7x7_split_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached split-bf16 weights when this convolution can run on the split-bf16 7x7 kernel (7x7 / stride 1
     or 2 / padding 3, one or two input channels, output channels a multiple of 8, float32), else None."""
-    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+    if not (_hand() and split_on() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
             and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (7, 7) and tuple(stride) in ((1, 1), (2, 2))
             and tuple(padding) == (3, 3) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
             and x.shape[1] in (1, 2) and weight.shape[0] % 8 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30
             and weight.shape[0] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
         return None
-    key = (weight._version, weight.data_ptr())
-    cached = getattr(weight, "_vo_conv7x7_split", None)
-    if cached is None or cached[0] != key:
-        cached = (key, ops.conv7x7_split_filter(weight))
-        weight._vo_conv7x7_split = cached
-    return cached[1]
+    return _split_cached(weight, "_vo_conv7x7_split", ops.conv7x7_split_filter)
 
 
 def _conv1x1s2_split_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached split-bf16 weights when this 1x1 stride-2 convolution (a residual stage's projection
     shortcut) can run on the split-bf16 direct kernel, else None."""
-    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+    if not (_hand() and split_on() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
             and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (1, 1) and tuple(stride) == (2, 2)
             and tuple(padding) == (0, 0) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
             and x.shape[1] % 16 == 0 and x.shape[3] % 2 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
@@ -277,19 +312,14 @@ def _conv1x1s2_split_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, 
     wo = (x.shape[3] - 1) // 2 + 1
     if wo < 0.6 * ((wo + 31) // 32 * 32):
         return None
-    key = (weight._version, weight.data_ptr())
-    cached = getattr(weight, "_vo_conv1x1s2_split", None)
-    if cached is None or cached[0] != key:
-        cached = (key, ops.conv1x1_split_filter(weight))
-        weight._vo_conv1x1s2_split = cached
-    return cached[1]
+    return _split_cached(weight, "_vo_conv1x1_split", ops.conv1x1_split_filter)
 
 
 def _conv3x3s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups):
     """The cached arranged weights when this convolution can run on the streaming 3x3 stride-2
     matrix-core kernel (float32, input channels a multiple of 8, an output width that fills the
     kernel's 32- or 64-pixel row segments to at least 60 %), else None."""
-    if not (_WINOGRAD and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
+    if not (_hand() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and weight.dtype == torch.float32
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] % 8 == 0
             and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
@@ -309,7 +339,7 @@ def _split_s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding
     """The cached split-bf16 weights when this 3x3 stride-2 convolution can run on the split-bf16 direct
     kernel (float32, input channels a multiple of 16, even input width, an output width that fills
     the kernel's 32-pixel row segments to at least 60 %), else None."""
-    if not (_WINOGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+    if not (_hand() and split_on() and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
             and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2)
             and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
             and x.shape[1] % 16 == 0 and x.shape[3] % 2 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31 - 1):
@@ -317,15 +347,8 @@ def _split_s2_weights_for(x: torch.Tensor, weight: torch.Tensor, stride, padding
     wo = (x.shape[3] - 1) // 2 + 1
     if wo < 0.6 * ((wo + 31) // 32 * 32):
         return None
-    key = (weight._version, weight.data_ptr())
-    table = getattr(weight, "_vo_winograd", None)            # the split filter of a 3x3 weight is shared with stride 1
-    if table is None or table[0] != key:
-        table = (key, {})
-        weight._vo_winograd = table
-    U = table[1].get(1)
-    if U is None:
-        U = table[1][1] = ops.conv3x3_split_filter(weight.contiguous())
-    return U
+    # the split filter of a 3x3 weight is shared with stride 1
+    return _split_cached(weight, "_vo_conv3x3_split", lambda w, pieces: ops.conv3x3_split_filter(w.contiguous(), pieces))
 
 
 def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
@@ -354,18 +377,14 @@ def conv2d_nobias(x: torch.Tensor, weight: torch.Tensor, stride=(1, 1), padding=
     if Wg is not None:
         return ops.conv3x3s2(x, Wg, weight.shape[0])
     ks = tuple(weight.shape[2:])
-    if (_WINOGRAD and ks in ((1, 5), (5, 1)) and tuple(padding) == (ks[0] // 2, ks[1] // 2) and tuple(stride) == (1, 1)
+    if (_hand() and ks in ((1, 5), (5, 1)) and tuple(padding) == (ks[0] // 2, ks[1] // 2) and tuple(stride) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and x.dtype == torch.float32 and weight.dtype == torch.float32
             and x.is_cuda and x.is_contiguous() and weight.shape[1] % 8 == 0 and weight.shape[0] >= 32
             and weight.shape[1] == x.shape[1]):
         key = (weight._version, weight.data_ptr())
-        if _SPLIT_BF16 and weight.shape[1] % 16 == 0 and x.shape[3] % 2 == 0:
-            # the separable GRU's gate convolutions on the split-bf16 direct kernel
-            cached = getattr(weight, "_vo_conv5_split", None)
-            if cached is None or cached[0] != key:
-                cached = (key, ops.conv5_split_filter(weight))
-                weight._vo_conv5_split = cached
-            return ops.conv5_split(x, cached[1], weight.shape[0], ks == (5, 1))
+        if split_on() and weight.shape[1] % 16 == 0 and x.shape[3] % 2 == 0:
+            # the separable GRU's gate convolutions on the split direct kernel
+            return ops.conv5_split(x, _split_cached(weight, "_vo_conv5_split", ops.conv5_split_filter), weight.shape[0], ks == (5, 1))
         # ... or as one-dimensional Winograd F(4,5) on the float32 matrix instructions
         cached = getattr(weight, "_vo_winograd1d", None)
         if cached is None or cached[0] != key:
@@ -426,7 +445,7 @@ def _conv_nobias(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
         Ws = _conv1x1s2_split_weights_for(x, w, conv.stride, conv.padding, conv.dilation, conv.groups)
         if Ws is not None:
             return ops.conv1x1s2_split(x, Ws, w.shape[0])
-        if (_WINOGRAD and conv.stride == (2, 2) and x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_cuda
+        if (_hand() and conv.stride == (2, 2) and x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_cuda
                 and x.is_contiguous() and x.shape[1] % 8 == 0 and conv.groups == 1 and conv.dilation == (1, 1)
                 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 30):
             wo = (x.shape[3] - 1) // 2 + 1
@@ -598,7 +617,7 @@ def _shortcut_fuses(x: torch.Tensor, conv3x3: nn.Conv2d, conv1x1: nn.Conv2d) -> 
     """True when a stride-2 block's 3x3 convolution and its projection shortcut can share one pass over x
     (ops.conv3x3s2_shortcut_split): same widths, an output width in multiples of 4, the split-bf16 arithmetic."""
     Wo = (x.shape[3] + 1) // 2
-    return (split_bf16_on() and x.is_contiguous() and conv3x3.out_channels == conv1x1.out_channels and x.shape[3] % 2 == 0
+    return (split_on() and x.is_contiguous() and conv3x3.out_channels == conv1x1.out_channels and x.shape[3] % 2 == 0
             and Wo % 4 == 0 and conv3x3.stride == (2, 2) and conv1x1.stride == (2, 2))
 
 

@@ -1,11 +1,13 @@
-"""RAFT-Flow and RAFT-Stereo with the correlation path on hand-written HIP kernels.
+"""RAFT-Flow and RAFT-Stereo on hand-written HIP kernels.
 
-The conv encoders and GRUs are PyTorch modules (MIOpen); the all-pairs
-correlation volume, its pyramid, the per-iteration windowed lookup and the final
-convex upsampling go through the C ABI in ``visual_odometry_amd.ops`` and exist
-only on the GPU.  Both models are inference-only (``test_mode`` of the published
-models): they return the low-resolution field and the upsampled field of the
-LAST iteration, and evaluate the mask head on that iteration only.
+The all-pairs correlation volume, its pyramid, the per-iteration windowed lookup and the final
+convex upsampling go through the C ABI in ``visual_odometry_amd.ops``; the conv encoders and GRUs
+are ``nn.Module`` trees that hold the parameters under the published names and dispatch their
+convolutions, norms and gate arithmetic to hand-written kernels of the same library (raft/layers.py,
+raft/update.py).  Nothing here runs without a GPU.  Both models are inference-only (``test_mode`` of
+the published models): they return the low-resolution field and the upsampled field of the LAST
+iteration, and evaluate the mask head on that iteration only.  ``conv_arithmetic`` (a field of each
+model: "f16x3", "bf16x3" or "f32", see layers.Arithmetic) says how the heavy products are formed.
 
 Argument sets: RAFT-Flow as flow/flow_map_RAFT.py:36-40 (full model, 4 levels,
 radius 4); RAFT-Stereo as stereo/stereo_disparity_RAFT.py:33-44, with
@@ -21,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import BasicEncoder, MultiBasicEncoder, conv_plain, fused_passes, split_bf16_on
+from .layers import CONV_ARITHMETICS, BasicEncoder, MultiBasicEncoder, arithmetic, conv_plain
 from .update import BasicMultiUpdateBlock, BasicUpdateBlock
 
 
@@ -40,6 +42,12 @@ def pixel_major(fmap: torch.Tensor) -> torch.Tensor:
     """(B,D,H,W) -> (B,H,W,D) contiguous float32: the layout the correlation kernel
     reads (each pixel's feature vector is one contiguous K-row)."""
     return fmap.float().permute(0, 2, 3, 1).contiguous()
+
+
+def _checked(kind: str) -> str:
+    if kind not in CONV_ARITHMETICS:
+        raise ValueError(f"conv_arithmetic must be one of {CONV_ARITHMETICS}, not {kind!r}")
+    return kind
 
 
 def load_checkpoint(model: nn.Module, path: str, device) -> None:
@@ -75,20 +83,25 @@ class RAFTFlow(nn.Module):
         # flow/flow_map_RAFT.py:38): float16 activations in the conv nets over float32
         # master weights; correlation, lookup, coordinates and upsampling stay float32.
         self.mixed_precision = False
+        self.conv_arithmetic = "f16x3"                       # see layers.Arithmetic.kind
 
     def _act_dtype(self):
         return torch.float16 if self.mixed_precision else torch.float32
 
+    def _scope(self):
+        """The arithmetic of this model's forward passes: its own ``conv_arithmetic``, fused kernels on."""
+        return arithmetic(_checked(self.conv_arithmetic), fused=True)
+
     def presplit_features(self) -> bool:
         """True when features() hands the correlation kernel rows that are already split into bf16
-        pieces (ops.split_feature_rows(., 32)): under the split-bf16 arithmetic, outside mixed precision.
+        pieces (ops.split_feature_rows(., 32)): under the "bf16x3" arithmetic, outside mixed precision.
         Such maps are bytes for that kernel, not float32 numbers."""
-        return split_bf16_on() and not self.mixed_precision
+        return self.conv_arithmetic == "bf16x3" and not self.mixed_precision
 
     @torch.no_grad()
     def features(self, images: torch.Tensor) -> torch.Tensor:
         """Normalised images (B,3,H,W) -> pixel-major feature maps (B,H/8,W/8,256); see presplit_features."""
-        with fused_passes():
+        with self._scope():
             return self.fnet(images.to(self._act_dtype()), pixel_major=True, split_rows=self.presplit_features())
 
     @torch.no_grad()
@@ -113,11 +126,11 @@ class RAFTFlow(nn.Module):
         if self.presplit_features():
             corr = ops.corr_volume_2d_presplit(fmap1.contiguous(), fmap2.contiguous())
         else:
-            corr = ops.corr_volume_2d(fmap1, fmap2, split=split_bf16_on())
+            corr = ops.corr_volume_2d(fmap1, fmap2, split=self.conv_arithmetic == "bf16x3")
         pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
 
         act = self._act_dtype()
-        with fused_passes():
+        with self._scope():
             net, inp = torch.split(self.cnet(image1.to(act)), [c.hidden_dim, c.context_dim], dim=1)
             net, inp = torch.tanh(net), torch.relu(inp)
 
@@ -130,7 +143,7 @@ class RAFTFlow(nn.Module):
         # the window's 324 channels are padded with zero planes to a multiple of 16 when the consuming 1x1
         # convolution runs on the split-bf16 kernel (which takes its input channels in chunks of 16)
         win_ch = c.corr_levels * (2 * c.corr_radius + 1) ** 2
-        pad_ch = (-win_ch) % 16 if (split_bf16_on() and act == torch.float32 and W8 % 2 == 0) else 0
+        pad_ch = (-win_ch) % 16 if (self.conv_arithmetic != "f32" and act == torch.float32 and W8 % 2 == 0) else 0
         window_buf = torch.empty((B, win_ch + pad_ch, H8, W8), device=image1.device, dtype=torch.float32)
         if pad_ch:
             window_buf[:, win_ch:].zero_()
@@ -138,7 +151,7 @@ class RAFTFlow(nn.Module):
             ops.corr_lookup_2d(pyramid, coords1.contiguous(), c.corr_radius, out=window_buf[:, :win_ch])
             window = window_buf
             flow = coords1 - coords0
-            with fused_passes():
+            with self._scope():
                 net, raw_mask, delta = self.update_block(net, inp, window.to(act), flow.to(act),
                                                          want_mask=(it == iters - 1), state=state)
             coords1 = coords1 + delta.float()
@@ -180,6 +193,10 @@ class RAFTStereo(nn.Module):
             [nn.Conv2d(context_dims[i], c.hidden_dims[i] * 3, 3, padding=1) for i in range(c.n_gru_layers)])
         self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=c.n_downsample)
         self.mixed_precision = False     # as in RAFTFlow (stereo/stereo_disparity_RAFT.py:43 leaves it off)
+        self.conv_arithmetic = "f16x3"   # see layers.Arithmetic.kind
+
+    def _scope(self):
+        return arithmetic(_checked(self.conv_arithmetic), fused=True)
 
     @torch.no_grad()
     def forward(self, image1, image2, iters: int = 12, flow_init=None, normalized: bool = False):
@@ -194,7 +211,7 @@ class RAFTStereo(nn.Module):
         B = image1.shape[0]
 
         act = torch.float16 if self.mixed_precision else torch.float32
-        with fused_passes():
+        with self._scope():
             image1, image2 = image1.to(act), image2.to(act)
             cnet_list = self.cnet(image1, num_layers=c.n_gru_layers)
             both = self.fnet(torch.cat([image1, image2], dim=0), pixel_major=True)
@@ -205,7 +222,7 @@ class RAFTStereo(nn.Module):
                         for i, conv in zip(inp_list, self.context_zqr_convs)]
         fmap1, fmap2 = both[:B], both[B:]
 
-        corr = ops.corr_volume_1d(fmap1, fmap2, split=split_bf16_on())
+        corr = ops.corr_volume_1d(fmap1, fmap2, split=self.conv_arithmetic == "bf16x3")
         pyramid = ops.corr_pyramid_1d(corr, c.corr_levels)
 
         _, _, h, w = net_list[0].shape
@@ -218,7 +235,7 @@ class RAFTStereo(nn.Module):
         for it in range(iters):
             window = ops.corr_lookup_1d(pyramid, coords1.contiguous(), c.corr_radius)
             flow = coords1 - coords0
-            with fused_passes():
+            with self._scope():
                 if c.n_gru_layers == 3 and c.slow_fast_gru:
                     net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False,
                                                  update=False, state=state)

@@ -1,6 +1,9 @@
-"""Recurrent update operators of RAFT and RAFT-Stereo (PyTorch-ROCm / MIOpen).
+"""Recurrent update operators of RAFT and RAFT-Stereo.
 
-Sub-module names follow the published models (``encoder.convc1``, ``gru.convz1``,
+``nn.Module`` trees for the parameters; inside a product forward pass a GRU step is two hand-written
+convolution kernels with the gate arithmetic in their stores, the motion encoders and heads run on the
+same kernel family (raft/layers.py), and the stock PyTorch operators below are what runs with the fused
+passes off.  Sub-module names follow the published models (``encoder.convc1``, ``gru.convz1``,
 ``flow_head.conv1``, ``mask.0`` ...) so trained state dicts load unchanged.  The
 only departure in behaviour is an optimisation that cannot change the result:
 the up-sampling mask head is evaluated only when the caller asks for it (the
@@ -14,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .layers import conv2d_nobias, conv_act, conv_plain, fused_on, padded_input_twin, split_bf16_on, weight_for
+from .layers import conv2d_nobias, conv_act, conv_plain, fused_on, padded_input_twin, split_on, split_pieces, weight_for
 
 
 def _merged_zr_weight(owner: nn.Module, tag: str, convz: nn.Conv2d, convr: nn.Conv2d, dtype) -> torch.Tensor:
@@ -35,8 +38,13 @@ def _split_gru_operands(owner, tag, convz, convr, convq, fold=None):
     lo..hi-1 carry a tensor that does not change over the refinement iterations; they are cut out of the
     step's weights and returned as separate (z|r, q) weights, whose convolution the caller evaluates once."""
     tensors = [convz.weight, convr.weight, convq.weight] + [c.bias for c in (convz, convr, convq) if c.bias is not None]
-    key = (fold,) + tuple((t._version, t.data_ptr()) for t in tensors)
-    cached = getattr(owner, "_vo_gru_split_" + tag, None)
+    pieces = split_pieces()
+    key = (fold, pieces) + tuple((t._version, t.data_ptr()) for t in tensors)
+    table = getattr(owner, "_vo_gru_split_" + tag, None)
+    if table is None:
+        table = {}
+        setattr(owner, "_vo_gru_split_" + tag, table)
+    cached = table.get(pieces)
     if cached is None or cached[0] != key:
         with torch.no_grad():
             wzr = torch.cat([convz.weight, convr.weight], dim=0).float()
@@ -47,13 +55,13 @@ def _split_gru_operands(owner, tag, convz, convr, convq, fold=None):
                 folded = (wzr[:, lo:hi].contiguous(), wq[:, lo:hi].contiguous())
                 wzr = torch.cat([wzr[:, :lo], wzr[:, hi:]], dim=1)
                 wq = torch.cat([wq[:, :lo], wq[:, hi:]], dim=1)
-            Uzr = ops.gru_split_filter(wzr.contiguous())
-            Uq = ops.gru_split_filter(wq.contiguous())
+            Uzr = ops.gru_split_filter(wzr.contiguous(), pieces)
+            Uq = ops.gru_split_filter(wq.contiguous(), pieces)
             bzr = None
             if convz.bias is not None and convr.bias is not None:
                 bzr = torch.cat([convz.bias, convr.bias]).float().contiguous()
         cached = (key, Uzr, bzr, Uq, folded)
-        setattr(owner, "_vo_gru_split_" + tag, cached)
+        table[pieces] = cached
     return cached[1], cached[2], cached[3], cached[4]
 
 
@@ -62,7 +70,7 @@ def _split_gru_eligible(h: torch.Tensor, in_channels: int, convz: nn.Conv2d, con
     with the gate arithmetic in their stores."""
     ks = tuple(convz.kernel_size)
     B, C, H, W = h.shape
-    return (split_bf16_on() and h.dtype == torch.float32 and h.is_cuda and h.is_contiguous() and C % 64 == 0
+    return (split_on() and h.dtype == torch.float32 and h.is_cuda and h.is_contiguous() and C % 64 == 0
             and in_channels % 16 == 0 and W % 4 == 0 and ks in ((3, 3), (1, 5), (5, 1))
             and tuple(convz.padding) == (ks[0] // 2, ks[1] // 2) and (convz.bias is None) == (convr.bias is None)
             and in_channels * H * W * 4 < 2 ** 31 - 1)

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .interfaces import OpticalFlowInterface, StereoDisparityInterface
-from .raft.models import RAFTFlow, RAFTFlowConfig, RAFTStereo, RAFTStereoConfig, load_checkpoint
+from .raft.models import RAFTFlow, RAFTFlowConfig, RAFTStereo, RAFTStereoConfig, _checked, load_checkpoint
 
 
 def _device() -> torch.device:
@@ -70,7 +70,7 @@ def gray_batch_to_rgb(frames: torch.Tensor) -> torch.Tensor:
 
 class HipOpticalFlowRAFT(OpticalFlowInterface):
     def __init__(self, checkpoint: Optional[str] = None, rectification=None, iters: int = 32, seed: int = 0,
-                 mixed_precision: bool = False):
+                 mixed_precision: bool = False, conv_arithmetic: str = "f16x3"):
         self.device = _device()
         self.iters = iters
         self.flow = None
@@ -81,6 +81,7 @@ class HipOpticalFlowRAFT(OpticalFlowInterface):
             load_checkpoint(self.model, checkpoint, self.device)
         self.model.to(self.device).eval()
         self.model.mixed_precision = bool(mixed_precision)      # flow/flow_map_RAFT.py:38 passes False
+        self.model.conv_arithmetic = _checked(conv_arithmetic)   # how the heavy float32 products are formed (raft.layers.Arithmetic)
 
     def compute_flow(self, img1, img2) -> np.ndarray:
         if img1 is None or img2 is None:
@@ -116,7 +117,8 @@ class HipOpticalFlowRAFT(OpticalFlowInterface):
 
 class HipDisparityRAFT(StereoDisparityInterface):
     def __init__(self, checkpoint: Optional[str] = None, rectification=None, iters: int = 32,
-                 config: Optional[RAFTStereoConfig] = None, seed: int = 1, mixed_precision: bool = False):
+                 config: Optional[RAFTStereoConfig] = None, seed: int = 1, mixed_precision: bool = False,
+                 conv_arithmetic: str = "f16x3"):
         self.device = _device()
         self.iters = iters
         self.flow = None
@@ -127,6 +129,7 @@ class HipDisparityRAFT(StereoDisparityInterface):
             load_checkpoint(self.model, checkpoint, self.device)
         self.model.to(self.device).eval()
         self.model.mixed_precision = bool(mixed_precision)      # stereo/stereo_disparity_RAFT.py:43 passes False
+        self.model.conv_arithmetic = _checked(conv_arithmetic)
 
     def compute_disparity(self, img_left, img_right) -> np.ndarray:
         if img_left is None or img_right is None:
