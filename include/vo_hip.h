@@ -234,7 +234,7 @@ int vo_conv1x1_bf16x3_filter(const float* weight, void* arranged, int K, int C, 
  * correlation window, the mask heads), where the float32 matrix instruction, not memory, bounds vo_conv1x1:
  * same weights, epilogue (scale / shift / ReLU) and channel-slice output as vo_conv3x3_bf16x3.  Layers with at least
  * 64 output channels in multiples of 8, planes of whole groups of four pixels and 16-byte aligned tensors run on a kernel that keeps
- * a block's weights in LDS (bf16 pieces; same bits in the result); use_template != 0 keeps them on the template's kernel
+ * a block's weights in LDS (same bits in the result); use_template != 0 keeps them on the template's kernel
  * (a switch for comparing the two). */
 int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride,
                       const float* scale, const float* shift, int relu,
@@ -388,7 +388,9 @@ int vo_corr_volume_1d(const float* fmap1, const float* fmap2, float* corr,
 /* The same two volumes with every float32 product assembled from three bf16 matrix-core terms
  * (al*bh + ah*bl + ah*bh, float32 accumulation: 16 significant bits per product, largest error about 5e-6 of
  * the largest entry; exact on small integers): the bf16 instruction runs at 16 times the float32 one's rate, so
- * the store of the volume becomes the bound. */
+ * the store of the volume becomes the bound.  These kernels (and the _presplit ones below) scale by the float32
+ * value 1/sqrt(D) where vo_corr_volume_* divide by sqrt(D): the same bits when D is a power of 4 (D = 256, the
+ * networks' width), one more rounding of 2^-24 otherwise -- far inside this arithmetic's 16 bits. */
 int vo_corr_volume_2d_bf16x3(const float* fmap1, const float* fmap2, float* corr,
                              int batch, int H, int W, int D, void* stream);
 int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, float* corr,
@@ -435,28 +437,6 @@ int vo_corr_lookup_2d(const float* l0, const float* l1, const float* l2, const f
 int vo_corr_lookup_1d(const float* l0, const float* l1, const float* l2, const float* l3,
                       const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W,
                       int W2, int levels, int radius, void* stream);
-
-/* ---------------------------------------------------------------------------
- * The 2-D pyramid in a TILED target order (the lookup's patches then cost about half the cache lines).
- * One source pixel's slice of a level of true size h x w: tiles of 8 columns x 4 rows (32 floats = one 128-byte
- * line), tiles_x = ceil(w/8), tiles_y = ceil(h/4), element (y,x) at ((y>>2)*tiles_x + (x>>3))*32 + (y&3)*8 + (x&7);
- * vo_tiled_slice_elements(h, w) = tiles_y*tiles_x*32.  Entries of a tile outside the true size are not values.
- *   vo_tile_feature_rows      fmap (B,H*W,D) -> (B, slice, D): the second feature map with its rows in tiled order
- *                             (zero rows for the padding); the correlation of fmap1 with it IS level 0, tiled:
- *   vo_corr_volume_mn         corr[b][m][n] = <f1[b,m,:], f2[b,n,:]> / sqrt(D) for M x N pixels (split != 0: bf16x3).
- *   vo_corr_pyramid_2d_tiled  levels 1..3 (tiled, sizes floor-halved) from tiled level 0 in one pass.
- *   vo_corr_lookup_2d_tiled   vo_corr_lookup_2d on tiled levels; identical results.
- * Same call sites in the reference as the row-major entry points above.
- * ------------------------------------------------------------------------- */
-int64_t vo_tiled_slice_elements(int H2, int W2);
-int vo_tile_feature_rows(const float* fmap, float* out, int batch, int H, int W, int D, void* stream);
-int vo_corr_volume_mn(const float* fmap1, const float* fmap2, float* corr, int batch, int M, int N, int D, int split,
-                      void* stream);
-int vo_corr_pyramid_2d_tiled(const float* l0, float* l1, float* l2, float* l3,
-                             int64_t images, int H2, int W2, void* stream);
-int vo_corr_lookup_2d_tiled(const float* l0, const float* l1, const float* l2, const float* l3,
-                            const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W,
-                            int H2, int W2, int levels, int radius, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Convex upsampling (RAFT.upsample_flow / RAFTStereo.upsample_flow).
@@ -574,7 +554,10 @@ int vo_pair_poses(const double* kp, int64_t kp_batch_stride,
  * VO_PAIR_POSES_STATIC_MAX_POINTS (VO_ERR_UNSUPPORTED beyond; use vo_pair_poses then).
  * The array (about 12.4 MiB) exists once per GPU the library runs on, for the life of the
  * process, and is shared by every call on that GPU: calls that overlap in time on one GPU
- * (different streams or threads) race on it -- order them on one stream. */
+ * (different streams or threads) race on it -- order them on one stream.  The FIRST call on
+ * each GPU looks the array's device address up (hipGetSymbolAddress, under a mutex): make that
+ * call outside any stream capture; every later call on that GPU only enqueues kernels and a
+ * memset on `stream` and may be captured into a HIP graph. */
 #define VO_PAIR_POSES_STATIC_MAX_BATCH  8192
 #define VO_PAIR_POSES_STATIC_MAX_POINTS 262144
 int vo_pair_poses_static(const double* kp, int64_t kp_batch_stride,

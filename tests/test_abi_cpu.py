@@ -151,3 +151,48 @@ def test_backends_subclass_the_reference_interfaces(cv2):
     r = subprocess.run([sys.executable, "-c", _DROP_IN_CHECK, _REFERENCE, ROOT, cv2], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def _call_arguments(text, start):
+    """The top-level arguments of the call whose opening parenthesis is at text[start]."""
+    depth, args, cur = 0, [], []
+    for ch in text[start:]:
+        if ch in "([{":
+            depth += 1
+            if depth == 1:
+                continue
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                args.append("".join(cur).strip())
+                return args
+        if ch == "," and depth == 1:
+            args.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(ch)
+    raise AssertionError("unbalanced call")
+
+
+def test_every_16_byte_buffer_store_has_a_literal_scalar_offset():
+    """A 16-byte buffer store whose scalar-offset operand lives in a register may store the NEW contents of its
+    data registers when a vector instruction overwrites them right behind it (the compiler inserts the wait states
+    only for a constant scalar offset; measured on gfx950: sporadically wrong lanes).  Every such store in the
+    library therefore passes an integer literal as its fourth argument -- this test reads the sources and fails
+    when one does not."""
+    import re
+    csrc = os.path.join(ROOT, "visual_odometry_amd", "csrc")
+    found = 0
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        text = re.sub(r"//[^\n]*", "", text)                      # comments mention the builtin too
+        for m in re.finditer(r"__builtin_amdgcn_raw_buffer_store_b128\s*\(", text):
+            args = _call_arguments(text, m.end() - 1)
+            assert len(args) == 5, (name, args)
+            assert re.fullmatch(r"\d+", args[3]), f"{name}: 16-byte buffer store with a non-literal scalar offset: {args[3]!r}"
+            found += 1
+        # the inline-assembly spelling of the same store must not appear at all
+        assert not re.search(r"buffer_store_dwordx4|buffer_store_b128\s+v", text), name
+    assert found >= 6                                               # the check did see the stores it is about

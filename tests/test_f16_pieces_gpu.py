@@ -180,6 +180,10 @@ def test_conv1x1_float16_pieces(vo, N, C, H, W, K):
     want = Fn.conv2d(x.double(), w.double(), None)
     got = ops.conv1x1_split(x, A, K)
     assert _err(got, want) < F32_GRADE_TOL
+    # the kernel with the weights resident in LDS (where the layer fits it) and the template's kernel: the same bits
+    assert torch.equal(got, ops.conv1x1_split(x, A, K, use_template=True))
+    sc = (_rand(K, seed=173).abs() + 0.5).to(DEV)
+    assert torch.equal(ops.conv1x1_split(x, A, K, sc, bias, True), ops.conv1x1_split(x, A, K, sc, bias, True, use_template=True))
     e32 = _err(ops.conv1x1(x, ops.conv1x1_filter(w), K), want)                               # float32 instruction, direct sum
     assert _err(got, want) < 3.0 * e32 + 2e-7
     pm = ops.conv1x1_pixel_major_split(x, A, K, None, bias, False)

@@ -352,3 +352,38 @@ def test_a_step_captures_into_a_hip_graph(vo):
     g.replay()
     torch.cuda.synchronize()
     assert (T1 - T2).abs().max().item() < 1e-5 and torch.equal(sk1, sk2) and (T2 - T0).abs().max().item() > 1e-3
+
+
+def test_long_sequence_in_many_chunks_keeps_memory_flat(vo):
+    """The long-sequence configuration's loop structure on one GPU: 120 frame pairs from PINNED HOST memory in 60
+    chunks of 2 (uploaded chunk by chunk on the copy stream, the halo depth carried from chunk to chunk,
+    test_camera_tracking.py:116,143-150) against the same sequence in 8 chunks of 15: same skip flags, the same
+    poses, the same composed trajectory; and the peak of device memory over the 60-chunk run is the peak of its
+    first few chunks -- nothing accumulates with the length of the sequence but the 128-byte pose rows."""
+    from visual_odometry_amd.pipeline import compose_trajectory
+    H, W, F = 96, 128, 121
+    pipe = _vo(H, W, iters=2)
+    left, right = syn.stereo_sequence(31, F, H, W)
+    lh, rh = torch.from_numpy(left).pin_memory(), torch.from_numpy(right).pin_memory()
+    pipe.run(lh[:7], rh[:7], chunk_pairs=2)                        # warm-up: caches of arranged weights, allocator pools
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    pipe.run(lh[:9], rh[:9], chunk_pairs=2)                        # 4 chunks
+    torch.cuda.synchronize()
+    peak_short = torch.cuda.max_memory_allocated() - base
+    torch.cuda.reset_peak_memory_stats()
+    T60, sk60 = pipe.run(lh, rh, chunk_pairs=2)                    # 60 chunks
+    torch.cuda.synchronize()
+    peak_long = torch.cuda.max_memory_allocated() - base
+    assert T60.shape == (F - 1, 4, 4) and sk60.shape == (F - 1,)
+    pose_bytes = (F - 1) * (16 * 8 + 1)
+    assert peak_long <= peak_short + 4 * pose_bytes + (1 << 20), (peak_short, peak_long)
+    T8, sk8 = pipe.run(lh, rh, chunk_pairs=15)
+    assert torch.equal(sk60, sk8)
+    ok = ~sk60
+    assert (T60[ok] - T8[ok]).abs().max().item() < 1e-4
+    G60 = compose_trajectory(T60.cpu().numpy(), sk60.cpu().numpy())
+    G8 = compose_trajectory(T8.cpu().numpy(), sk8.cpu().numpy())
+    assert np.abs(G60[-1] - G8[-1]).max() < 2e-3                   # 120 products of poses that agree to 1e-4
+    assert np.abs(G60[-1][:3, :3] @ G60[-1][:3, :3].T - np.eye(3)).max() < 1e-9

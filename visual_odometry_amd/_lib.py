@@ -71,10 +71,6 @@ SIGNATURES = {
     "vo_split_feature_rows": [_P, _P, _L, _I, _I, _P],
     "vo_corr_volume_2d_presplit": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_1d_presplit": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vo_tile_feature_rows": [_P, _P, _I, _I, _I, _I, _P],
-    "vo_corr_volume_mn": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vo_corr_pyramid_2d_tiled": [_P, _P, _P, _P, _L, _I, _I, _P],
-    "vo_corr_lookup_2d_tiled": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_corr_pyramid_2d": [_P, _P, _P, _P, _L, _I, _I, _P],
     "vo_corr_pyramid_1d": [_P, _P, _P, _P, _L, _I, _P],
     "vo_corr_lookup_2d": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -93,7 +89,7 @@ SIGNATURES = {
     "vo_ransac_kabsch_batch": [_P, _P, _P, _D, _I, c_uint64, _P, _P, _P, _I, _I, _L, _P],
 }
 # entry points that return a size instead of a status
-SIZE_QUERIES = {"vo_pair_poses_workspace_bytes": [_I, _I], "vo_tiled_slice_elements": [_I, _I]}
+SIZE_QUERIES = {"vo_pair_poses_workspace_bytes": [_I, _I]}
 EXPORTS = sorted(list(SIGNATURES) + list(SIZE_QUERIES) + ["vo_version", "vo_last_error"])
 
 _lib = None

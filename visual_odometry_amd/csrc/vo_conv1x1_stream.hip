@@ -1,6 +1,6 @@
 // 1x1 stride-1 convolution with many channels on both sides, float32 in and out (NCHW), every product from three
-// bf16 matrix-core terms (see vo_conv_bf16x3.hip for the arithmetic; same weights image, same order of terms, the
-// same bits in the result): the motion encoder's first layer (correlation window -> 256 channels, every refinement
+// 16-bit matrix-core terms (bf16 or float16 pieces, see vo_pieces.h and vo_conv_split.h for the arithmetic; same
+// weights image, same order of terms, the same bits in the result as the template's kernel): the motion encoder's first layer (correlation window -> 256 channels, every refinement
 // iteration) and the mask head's last layer.
 //
 // A 1x1 layer has one tap: 24 matrix instructions per chunk of 16 input channels and wave, against 216 for a 3x3
@@ -20,15 +20,9 @@
 // most 8 bytes are not affected; every 16-byte buffer store of this library passes a constant 0 as scalar offset.
 // tests/test_raft_ops_gpu.py keeps this kernel under a bit-for-bit comparison with the template's.
 #include "vo_common.h"
+#include "vo_pieces.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int CK = 16;                        // input channels per chunk (the k of one matrix instruction)
 constexpr int KB = 64;                        // output channels per workgroup
@@ -37,13 +31,9 @@ constexpr int NTL = 2;                        // pixel tiles of 32 pixels per wa
 constexpr int PW = 32 * NTL;                  // pixels per wave
 constexpr int WAVES = 8;
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
+struct StreamEp { const float* scale; const float* shift; int relu; int64_t y_batch_stride; float unscale; };
 
-struct StreamEp { const float* scale; const float* shift; int relu; int64_t y_batch_stride; };
-
+template <typename PC>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
                                                                      float* __restrict__ y, StreamEp ep, int C, int P, int K,
                                                                      int kblocks, int ptiles, int items, int groups) {
@@ -89,28 +79,30 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const flo
         };
         auto multiply = [&](const u32x2 (&b)[8], int chunk) {
             const unsigned char* a = a_lds + chunk * A_CHUNK;
-            bf16x8 fa[2][2];
+            u32x4 fa[2][2], fs[2];
 #pragma unroll
             for (int part = 0; part < 2; ++part)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) fa[part][mt] = *reinterpret_cast<const bf16x8*>(a + (part * 2 + mt) * 1024);
+                for (int mt = 0; mt < 2; ++mt) fa[part][mt] = *reinterpret_cast<const u32x4*>(a + (part * 2 + mt) * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) fs[mt] = PC::for_low_input(fa[0][mt]);
 #pragma unroll
             for (int t = 0; t < NTL; ++t) {
                 u32x4 hi, lo;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const float va = __uint_as_float(b[2 * jj][t]), vb = __uint_as_float(b[2 * jj + 1][t]);
-                    const unsigned h = pack_bf16(va, vb);
+                    unsigned h, l;
+                    PC::cut(__uint_as_float(b[2 * jj][t]), __uint_as_float(b[2 * jj + 1][t]), h, l);
                     hi[jj] = h;
-                    lo[jj] = pack_bf16(va - __uint_as_float(h << 16), vb - __uint_as_float(h & 0xffff0000u));
+                    lo[jj] = l;
                 }
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, hi), xl = __builtin_bit_cast(bf16x8, lo);
+                const u32x4 xh = hi, xl = lo;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     // the small terms first, so that they are not rounded away against the large one
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][mt], xh, acc[mt][t], 0, 0, 0);
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mt], xl, acc[mt][t], 0, 0, 0);
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][mt], xh, acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = PC::mfma(fa[1][mt], xh, acc[mt][t]);
+                    acc[mt][t] = PC::mfma(fs[mt], xl, acc[mt][t]);
+                    acc[mt][t] = PC::mfma(fa[0][mt], xh, acc[mt][t]);
                 }
             }
         };
@@ -120,6 +112,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const flo
             multiply(b0, chunk);
             load(b0, chunk + 2);
             if (chunk + 1 < nchunks) multiply(b1, chunk + 1);
+        }
+
+        if constexpr (PC::F16) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) acc[mt][t] *= ep.unscale;      // back to the weights' own scale (a power of two)
         }
 
         // C/D layout of a 32x32 tile: pixel = lane & 31 (pixel p0 + t of this lane in tile t), channel row =
@@ -140,10 +139,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const flo
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ku = kb * KB + mt * 32 + (e & 3) + 8 * (e >> 2);           // + 4 * kk
-                // both loads always go out (an empty descriptor returns zeros): no load sits behind a branch
-                const float sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(scr, kk * 16, ku * 4, 0));
+                // both loads always go out (an empty descriptor returns zeros): no load sits behind a branch.  The range
+                // check covers the lane's part of the address only, so the scalar part is kept inside the K entries by
+                // hand: rows past K (a partial last channel block; K is a multiple of 8) read row K - 8 + 4*kk instead,
+                // and are never stored
+                const int kc = ku < K - 8 ? ku : K - 8;
+                const float sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(scr, kk * 16, kc * 4, 0));
                 scv[e] = ep.scale ? sv : 1.0f;
-                shv[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(shr, kk * 16, ku * 4, 0));      // 0 without a shift
+                shv[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(shr, kk * 16, kc * 4, 0));      // 0 without a shift
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -172,7 +175,7 @@ bool vo_conv1x1_stream_fits(int C, int64_t P, int K) {
 }
 
 int vo_conv1x1_stream_launch(const char* name, const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
-                             const float* shift, int relu, int N, int C, int64_t P, int K, hipStream_t st) {
+                             const float* shift, int relu, int N, int C, int64_t P, int K, int pieces, int weight_exp, hipStream_t st) {
     if (!x || !arranged || !y) return vo_fail(VO_ERR_INVALID_ARG, "%s: null pointer", name);
     if (N <= 0 || C <= 0 || P <= 0 || K <= 0) return vo_fail(VO_ERR_INVALID_ARG, "%s: bad sizes", name);
     if (scale && !shift) return vo_fail(VO_ERR_INVALID_ARG, "%s: scale without shift", name);
@@ -202,11 +205,18 @@ int vo_conv1x1_stream_launch(const char* name, const float* x, const void* arran
     if (per_xcd > need) per_xcd = (int)need;
     const int groups = 8 * per_xcd;
     const int lds = (C / CK) * A_CHUNK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const bool f16 = pieces == VO_PIECES_F16;
+    hipError_t e = hipFuncSetAttribute(f16 ? reinterpret_cast<const void*>(conv1x1_stream_kernel<PiecesF16>)
+                                           : reinterpret_cast<const void*>(conv1x1_stream_kernel<PiecesBf16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: LDS attribute: %s", name, hipGetErrorString(e));
-    const StreamEp ep{scale, shift, relu, y_batch_stride};
-    conv1x1_stream_kernel<<<dim3((unsigned)(groups * kblocks)), dim3(64 * WAVES), lds, st>>>(
-        x, static_cast<const unsigned short*>(arranged), y, ep, C, (int)P, K, kblocks, (int)ptiles, (int)items, groups);
+    const StreamEp ep{scale, shift, relu, y_batch_stride, f16 ? ldexpf(1.0f, -weight_exp) : 1.0f};
+    if (f16)
+        conv1x1_stream_kernel<PiecesF16><<<dim3((unsigned)(groups * kblocks)), dim3(64 * WAVES), lds, st>>>(
+            x, static_cast<const unsigned short*>(arranged), y, ep, C, (int)P, K, kblocks, (int)ptiles, (int)items, groups);
+    else
+        conv1x1_stream_kernel<PiecesBf16><<<dim3((unsigned)(groups * kblocks)), dim3(64 * WAVES), lds, st>>>(
+            x, static_cast<const unsigned short*>(arranged), y, ep, C, (int)P, K, kblocks, (int)ptiles, (int)items, groups);
     e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e));
     return VO_OK;

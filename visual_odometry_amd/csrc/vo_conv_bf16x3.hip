@@ -98,21 +98,21 @@ extern "C" int vo_gru_conv_q_bf16x3(const float* x, const float* rh, const void*
                               C, shape, 0, stream);
 }
 
-// vo_conv1x1_stream.hip: the same layer (bf16 pieces) with the channel block's weights resident in LDS (same weights image,
+// vo_conv1x1_stream.hip: the same layer with the channel block's weights resident in LDS (same weights image,
 // same bits); ``use_template`` = 1 keeps the layer on the template (for comparisons of the two kernels)
 bool vo_conv1x1_stream_fits(int C, int64_t P, int K);
 int vo_conv1x1_stream_launch(const char* name, const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
-                             const float* shift, int relu, int N, int C, int64_t P, int K, hipStream_t st);
+                             const float* shift, int relu, int N, int C, int64_t P, int K, int pieces, int weight_exp, hipStream_t st);
 
 extern "C" int vo_conv1x1_bf16x3(const float* x, const void* arranged, float* y, int64_t y_batch_stride, const float* scale,
                                  const float* shift, int relu, int N, int C, int H, int W, int K, int pieces, int weight_exp,
                                  int use_template, void* stream) {
     VO_PIECES_CHECK("vo_conv1x1_bf16x3", pieces, weight_exp);
-    if (pieces) return F16::conv1x1("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, N, C, H, W, K, weight_exp, 0, stream);
     if (!use_template && H > 0 && W > 0 && vo_conv1x1_stream_fits(C, (int64_t)H * W, K) &&
         ((reinterpret_cast<uintptr_t>(arranged) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && (y_batch_stride & 3) == 0)
         return vo_conv1x1_stream_launch("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, N, C, (int64_t)H * W, K,
-                                        vo_stream(stream));
+                                        pieces, weight_exp, vo_stream(stream));
+    if (pieces) return F16::conv1x1("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, N, C, H, W, K, weight_exp, 0, stream);
     return Bf::conv1x1("vo_conv1x1_bf16x3", x, arranged, y, y_batch_stride, scale, shift, relu, N, C, H, W, K, 0, 0, stream);
 }
 

@@ -228,7 +228,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N >= 8 ? 1 
 #undef VO_LOAD_SLICE
 #undef VO_STORE_SLICE
 
-    const float inv_divisor = 1.0f / divisor;                    // SPLIT: no bit-for-bit claim to keep, one multiplication
+    // SPLIT: a multiplication by the rounded reciprocal instead of the float32 path's division -- the same bits when
+    // sqrt(D) is a power of two (D = 256), one more rounding of 2^-24 otherwise, far inside three bf16 terms' 16 bits
+    const float inv_divisor = 1.0f / divisor;
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(Cg) & 15) == 0) {
         // Every tile passes through a 4 KiB LDS slot of its wave, after which a lane holds four consecutive
@@ -580,14 +582,6 @@ extern "C" int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, 
     VO_REQUIRE((int64_t)batch * H <= 0x7fffffffLL, "vo_corr_volume_1d_bf16x3: batch*H too large");
     return corr_abt(fmap1, fmap2, corr, batch * H, W1, W2, D, (int64_t)W1 * D, (int64_t)W2 * D, (int64_t)W1 * W2,
                     vo_stream(stream), "vo_corr_volume_1d_bf16x3", 1);
-}
-
-extern "C" int vo_corr_volume_mn(const float* fmap1, const float* fmap2, float* corr, int batch, int M, int N, int D, int split,
-                                 void* stream) {
-    VO_REQUIRE(M > 0 && N > 0, "vo_corr_volume_mn: bad size M=%d N=%d", M, N);
-    VO_REQUIRE(M <= (1 << 20) && N <= (1 << 21), "vo_corr_volume_mn: matrix sides beyond the supported 2^20 x 2^21");
-    return corr_abt(fmap1, fmap2, corr, batch, M, N, D, (int64_t)M * D, (int64_t)N * D, (int64_t)M * N, vo_stream(stream),
-                    "vo_corr_volume_mn", split != 0 ? 1 : 0);
 }
 
 extern "C" int vo_split_feature_rows(const float* x, void* out, int64_t rows, int D, int block, void* stream) {

@@ -1008,75 +1008,6 @@ def corr_lookup_1d(pyr, coords: torch.Tensor, radius: int = 4, out: torch.Tensor
     return out
 
 
-# ---- the 2-D pyramid in tiled target order (8 columns x 4 rows per 128-byte line)
-
-def tiled_slice_elements(h: int, w: int) -> int:
-    """Floats of one source pixel's slice of a tiled level of true size h x w."""
-    return ((h + 3) // 4) * ((w + 7) // 8) * 32
-
-
-def untile_volume(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
-    """(..., slice) tiled -> (..., h, w) row-major (a host-side convenience for tests and debugging)."""
-    tx = (w + 7) // 8
-    y, x = torch.meshgrid(torch.arange(h, device=t.device), torch.arange(w, device=t.device), indexing="ij")
-    idx = ((y // 4) * tx + x // 8) * 32 + (y % 4) * 8 + (x % 8)
-    return t[..., idx.reshape(-1)].reshape(*t.shape[:-1], h, w)
-
-
-def corr_volume_2d_tiled(fmap1: torch.Tensor, fmap2: torch.Tensor, split: bool = False) -> torch.Tensor:
-    """corr_volume_2d with the target pixels in tiled order: (B, H*W, slice) float32, level 0 of the tiled
-    pyramid.  The second feature map's rows are put into tiled order first (zero rows for the padding), so the
-    correlation kernel itself is unchanged."""
-    B, H, W, D = fmap1.shape
-    if fmap2.shape != fmap1.shape:
-        raise ValueError("fmap1 and fmap2 must have the same shape")
-    sl = tiled_slice_elements(H, W)
-    f2t = torch.empty((B, sl, D), device=fmap2.device, dtype=torch.float32)
-    _call("vo_tile_feature_rows", _dev(fmap2, "fmap2", torch.float32), f2t.data_ptr(), B, H, W, D, _stream(),
-          nbytes=4 * (fmap2.numel() + f2t.numel()))
-    corr = torch.empty((B, H * W, sl), device=fmap1.device, dtype=torch.float32)
-    _call("vo_corr_volume_mn", _dev(fmap1, "fmap1", torch.float32), f2t.data_ptr(), corr.data_ptr(), B, H * W, sl, D,
-          int(bool(split)), _stream(), nbytes=4 * (fmap1.numel() + f2t.numel() + corr.numel()),
-          flops=(6 if split else 2) * B * H * W * sl * D)
-    return corr
-
-
-def corr_pyramid_2d_tiled(corr: torch.Tensor, size, levels: int = MAX_LEVELS):
-    """[level 0 .. level levels-1], each (B, N, slice_l) tiled; ``size`` = (H2, W2) of level 0."""
-    B, N, sl = corr.shape
-    shapes = pyramid_shapes_2d(size[0], size[1], levels)
-    if sl != tiled_slice_elements(*shapes[0]):
-        raise ValueError("corr does not have the tiled slice size of its (H2, W2)")
-    if any(h <= 0 or w <= 0 for h, w in shapes):
-        raise ValueError("a pyramid level is empty")
-    out = [corr] + [torch.empty((B, N, tiled_slice_elements(h, w)), device=corr.device, dtype=torch.float32) for h, w in shapes[1:]]
-    ptrs = [t.data_ptr() for t in out[1:]] + [0] * (MAX_LEVELS - levels)
-    _call("vo_corr_pyramid_2d_tiled", _dev(corr, "corr", torch.float32), *ptrs, B * N, size[0], size[1], _stream(),
-          nbytes=4 * sum(t.numel() for t in out))
-    return out
-
-
-def corr_lookup_2d_tiled(pyr, size, coords: torch.Tensor, radius: int = 4, out: torch.Tensor | None = None) -> torch.Tensor:
-    """corr_lookup_2d on the tiled pyramid (identical values): -> (B, L*(2r+1)^2, H, W); ``size`` = (H2, W2)."""
-    B, two, H, W = coords.shape
-    N = pyr[0].shape[1]
-    if two != 2 or N != H * W or pyr[0].shape[0] != B:
-        raise ValueError("coords must be (B,2,H,W) with H*W source pixels matching the pyramid")
-    for i, (h, w) in enumerate(pyramid_shapes_2d(size[0], size[1], len(pyr))):
-        if tuple(pyr[i].shape) != (B, N, tiled_slice_elements(h, w)):
-            raise ValueError(f"pyramid level {i} has shape {tuple(pyr[i].shape)}, expected {(B, N, tiled_slice_elements(h, w))}")
-    win = 2 * radius + 1
-    ch = len(pyr) * win * win
-    if out is None:
-        out = torch.empty((B, ch, H, W), device=coords.device, dtype=torch.float32)
-    elif tuple(out.shape) != (B, ch, H, W) or out.dtype != torch.float32:
-        raise ValueError("out has the wrong shape")
-    po, so = _slice(out, "out")
-    _call("vo_corr_lookup_2d_tiled", *_level_ptrs(pyr), _dev(coords, "coords", torch.float32), po, so, B, H, W, size[0], size[1],
-          len(pyr), radius, _stream(), nbytes=4 * B * H * W * (2 + len(pyr) * (win * win + (win + 1) ** 2)))
-    return out
-
-
 def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, factor: int, out_channels: int | None = None,
                     mask_scale: float = 1.0) -> torch.Tensor:
     """Convex-combination upsampling -> (B, Cout, f*H, f*W)."""

@@ -121,8 +121,8 @@ class RAFTFlow(nn.Module):
             fmap1, fmap2 = both[: image1.shape[0]], both[image1.shape[0]:]
         B, H8, W8, _ = fmap1.shape
 
-        # row-major target order: the tiled order (ops.corr_*_tiled) gives identical values but was measured
-        # slower and heavier on the memory counters for the lookup's gathers
+        # row-major target order: a tiled order (8x4-pixel tiles per 128-byte line) gives identical values but
+        # was measured slower and heavier on the memory counters for the lookup's gathers (tools/tiled_volume.hip.txt)
         if self.presplit_features():
             corr = ops.corr_volume_2d_presplit(fmap1.contiguous(), fmap2.contiguous())
         else:
