@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv1x1_stream_kernel(const flo
                 const int ku = kb * KB + mt * 32 + (e & 3) + 8 * (e >> 2);           // + 4 * kk
                 // both loads always go out (an empty descriptor returns zeros): no load sits behind a branch.  The range
                 // check covers the lane's part of the address only, so the scalar part is kept inside the K entries by
-                // hand: rows past K (a partial last channel block; K is a multiple of 8) read row K - 8 + 4*kk instead,
-                // and are never stored
-                const int kc = ku < K - 8 ? ku : K - 8;
+                // hand: rows past K (a partial last channel block; K is a multiple of 8, so ku < K means ku + 4 < K too)
+                // read row K - 8 + 4*kk instead, and are never stored
+                const int kc = ku < K ? ku : K - 8;
                 const float sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(scr, kk * 16, kc * 4, 0));
                 scv[e] = ep.scale ? sv : 1.0f;
                 shv[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(shr, kk * 16, kc * 4, 0));      // 0 without a shift
