@@ -12,7 +12,7 @@ t0, t1 = int(rows[idx[-2]]["Start_Timestamp"]), int(rows[idx[-1]]["Start_Timesta
 seg = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 d, c = collections.Counter(), collections.Counter()
 for r in seg:
-    n = r["Kernel_Name"][:90]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:90]
     d[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); c[n] += 1
 tot = sum(d.values())
 print(f"step wall {(t1 - t0) / 1e6:.2f} ms, busy {tot / 1e6:.2f} ms, {len(seg)} kernels")
