@@ -98,15 +98,16 @@ PMC_KEYS = {"vo_corr_volume_2d": "corr2d", "vo_corr_volume_1d": "corr1d", "vo_co
             "vo_instance_norm_apply": "instnorm_apply", "vo_conv1x1": "conv1x1"}
 
 
-def pmc_traffic(kernel: str, B: int, H: int, W: int):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE
-    and WRITE_SIZE collected separately; FETCH_SIZE doubled per the gfx950 correction
-    for wide reads), or None when no pass exists for this kernel and shape."""
+def pmc_traffic(kernel: str, B: int, H: int, W: int, arithmetic: str = "f16x3"):
+    """HBM-side bytes per launch from the COMMITTED rocprofv3 --pmc passes over this same workload
+    (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs; FETCH_SIZE doubled per
+    the gfx950 correction for wide reads) -- read from that file, not measured in this run --, or None when no
+    pass exists for this kernel, shape and arithmetic."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path) or kernel not in PMC_KEYS:
         return None
     meta = json.load(open(path))
-    if (meta.get("batch_pairs"), meta.get("height"), meta.get("width")) != (B, H, W):
+    if (meta.get("batch_pairs"), meta.get("height"), meta.get("width"), meta.get("conv_arithmetic", "bf16x3")) != (B, H, W, arithmetic):
         return None
     k = meta["kernels"].get(PMC_KEYS[kernel])
     if not k:
@@ -274,7 +275,7 @@ def config_leg(make, left, right, steps, what):
             "dtype": "f32", "config": what, "peak_device_memory_GiB": peak}
 
 
-def mfma_util_from_profile(kernel_key, B, H, W):
+def mfma_util_from_profile(kernel_key, B, H, W, arithmetic="f16x3"):
     """SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x GRBM_GUI_ACTIVE / 8) of the committed counter pass, or
     None when the pass was taken at another shape."""
     for name in ("mfma_util.json",):
@@ -283,7 +284,8 @@ def mfma_util_from_profile(kernel_key, B, H, W):
             continue
         meta = json.load(open(path))
         k = meta.get("kernels", {}).get(kernel_key)
-        if k and (meta.get("batch_pairs"), meta.get("height"), meta.get("width")) == (B, H, W) and "mfma_busy_frac" in k:
+        if (k and (meta.get("batch_pairs"), meta.get("height"), meta.get("width"), meta.get("conv_arithmetic", "bf16x3")) == (B, H, W, arithmetic)
+                and "mfma_busy_frac" in k):
             return {"value": k["mfma_busy_frac"], "batch_pairs_of_the_pass": meta.get("batch_pairs"),
                     "source": "profiles/" + name}
     return None
@@ -460,15 +462,19 @@ def main():
                     "avg_launch_us": d["avg_us"], "hbm_GBps": d.get("GBps")}
         if dom in SPLIT_BF16_KERNELS:
             roofline["float32_equivalent_TFLOPs"] = d["TFLOPs"] / 3.0
-            roofline["note"] = ("mean over all launches of one step; achieved counts the bf16 multiply-adds the kernel issues "
-                                "(three per float32 product: xl*wh + xh*wl + xh*wh), peak is the dense bf16 matrix rate; "
-                                "float32_equivalent_TFLOPs = the direct convolution's own FLOPs per second (f32 MFMA peak: 157.3)")
+            roofline["note"] = ("mean over all launches of one step; achieved counts the 16-bit multiply-adds the kernel issues "
+                                "(three per float32 product: xl*wh + xh*wl + xh*wh; float16 or bf16 pieces, the same instruction "
+                                "rate), peak is the dense 16-bit matrix rate; float32_equivalent_TFLOPs = the direct "
+                                "convolution's own FLOPs per second (f32 MFMA peak: 157.3)")
     else:
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
-    roofline["traffic"] = pmc_traffic(dom, B, H, W)
-    if dom in PMC_KEYS and mfma_util_from_profile(PMC_KEYS[dom], B, H, W):
-        roofline["mfma_busy_pmc"] = mfma_util_from_profile(PMC_KEYS[dom], B, H, W)
+    AR = args.conv_arithmetic
+    roofline["traffic"] = pmc_traffic(dom, B, H, W, AR)
+    roofline["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload "
+                                  "(tools/collect_profiles_r03.sh), committed with the repository, not measured in this run")
+    if dom in PMC_KEYS and mfma_util_from_profile(PMC_KEYS[dom], B, H, W, AR):
+        roofline["mfma_busy_pmc"] = mfma_util_from_profile(PMC_KEYS[dom], B, H, W, AR)
     if dom in ("vo_conv3x3_winograd", "vo_conv3x3_winograd4"):
         # flops are the multiply-adds the kernel issues in the Winograd domain: 16 per 2x2 outputs
         # (4/9 of the direct form) for F(2x2,3x3), 36 per 4x4 outputs (1/4) for F(4x4,3x3)
@@ -480,15 +486,15 @@ def main():
     if ck:
         roofline_corr = {"kernel": "vo_corr_volume_2d", "bound": "mfma", "achieved": ck["TFLOPs"],
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ck["TFLOPs"] / F32_MFMA_PEAK_TFLOPS,
-                         "avg_launch_us": ck["avg_us"], "traffic": pmc_traffic("vo_corr_volume_2d", B, H, W),
-                         "mfma_util_pmc": mfma_util_from_profile("corr2d", B, H, W)}
+                         "avg_launch_us": ck["avg_us"], "traffic": pmc_traffic("vo_corr_volume_2d", B, H, W, AR),
+                         "mfma_util_pmc": mfma_util_from_profile("corr2d", B, H, W, AR)}
     cs = kernels.get("vo_corr_volume_2d_bf16x3")
     if cs:
         # with bf16 terms the contraction's bound is the store of the volume, not the matrix cores
         roofline_corr = {"kernel": "vo_corr_volume_2d_bf16x3", "bound": "hbm", "achieved": cs["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": cs["GBps"] / HBM_PEAK_GBS, "avg_launch_us": cs["avg_us"],
                          "bf16_TFLOPs": cs["TFLOPs"], "float32_equivalent_TFLOPs": cs["TFLOPs"] / 3.0,
-                         "traffic": pmc_traffic("vo_corr_volume_2d_bf16x3", B, H, W),
+                         "traffic": pmc_traffic("vo_corr_volume_2d_bf16x3", B, H, W, AR),
                          "note": "split-bf16 products (three bf16 matrix-core terms per float32 product); the float32-instruction "
                                  "kernel's figures are in the f32_mfma_only leg's run (--conv-arithmetic f32)"}
     cp = kernels.get("vo_corr_volume_2d_presplit")
@@ -498,8 +504,8 @@ def main():
         roofline_corr = {"kernel": "vo_corr_volume_2d_presplit", "bound": "mfma", "achieved": cp["TFLOPs"], "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": cp["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS, "avg_launch_us": cp["avg_us"],
                          "float32_equivalent_TFLOPs": cp["TFLOPs"] / 3.0, "hbm_GBps": cp["GBps"],
-                         "hbm_frac": cp["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic("vo_corr_volume_2d_presplit", B, H, W),
-                         "mfma_busy_pmc": mfma_util_from_profile("corr2d_presplit", B, H, W),
+                         "hbm_frac": cp["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic("vo_corr_volume_2d_presplit", B, H, W, AR),
+                         "mfma_busy_pmc": mfma_util_from_profile("corr2d_presplit", B, H, W, AR),
                          "note": "split-bf16 products (three bf16 matrix-core terms per float32 product) on feature rows split into "
                                  "their bf16 pieces by the encoder's last layer; achieved counts the bf16 multiply-adds issued; "
                                  "the float32-instruction kernel's figures are in the f32_mfma_only leg's run (--conv-arithmetic f32)"}

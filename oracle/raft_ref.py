@@ -160,14 +160,14 @@ def _twin(model, make, device):
 
 
 @torch.no_grad()
-def raft_flow_forward(model, image1, image2, iters=12):
+def raft_flow_forward(model, image1, image2, iters=12, flow_init=None):
     """(flow at 1/8 resolution, full-resolution flow) from the restated RAFT carrying ``model``'s weights."""
     from . import raft_modules
-    return _twin(model, raft_modules.flow_twin, image1.device)(image1.float(), image2.float(), iters)
+    return _twin(model, raft_modules.flow_twin, image1.device)(image1.float(), image2.float(), iters, flow_init)
 
 
 @torch.no_grad()
-def raft_stereo_forward(model, image1, image2, iters=12):
+def raft_stereo_forward(model, image1, image2, iters=12, flow_init=None):
     """(x-flow field at working resolution, full-resolution disparity) from the restated RAFT-Stereo."""
     from . import raft_modules
-    return _twin(model, raft_modules.stereo_twin, image1.device)(image1.float(), image2.float(), iters)
+    return _twin(model, raft_modules.stereo_twin, image1.device)(image1.float(), image2.float(), iters, flow_init)

@@ -356,6 +356,62 @@ def test_raft_stereo_end_to_end(vo, H, W, iters, realtime):
     assert float(disp.abs().max()) > 1e-3
 
 
+def test_networks_end_to_end_from_large_initial_displacements(vo):
+    """Both networks started from a LARGE initial field (up to 20 cells = 160 px of flow, 30 cells = 120 px of
+    disparity, many windows partly or wholly outside the volume, every pyramid level sampled far from its
+    diagonal) against the restated networks started from the same field: the coordinates the lookups see are
+    nothing like the near-identity ones of a zero start."""
+    from visual_odometry_amd.raft.models import RAFTFlow, RAFTStereo, RAFTStereoConfig
+    torch.manual_seed(21)
+    flow, stereo = RAFTFlow().to(DEV).eval(), RAFTStereo(RAFTStereoConfig.realtime()).to(DEV).eval()
+    H, W = 256, 320
+    left, right = _images(2, H, W, seed=9)
+    g = torch.Generator().manual_seed(5)
+    f0 = ((torch.rand(2, 2, H // 8, W // 8, generator=g) - 0.5) * 40.0).to(DEV)
+    f0[:, :, :2] += 25.0                                          # two rows of windows pushed past the border
+    _, up = flow(left[:2], left[1:3], iters=5, flow_init=f0)
+    lo_ref, up_ref = raft_ref.raft_flow_forward(flow, left[:2], left[1:3], iters=5, flow_init=f0)
+    assert float(lo_ref.abs().max()) > 15.0                       # the field stayed large
+    assert _epe(up, up_ref) < 1e-3 and (up - up_ref).abs().max().item() < 0.05
+    d0 = torch.zeros(2, 2, H // 4, W // 4, device=DEV)
+    d0[:, 0] = -((torch.rand(2, H // 4, W // 4, generator=g)) * 30.0).to(DEV)
+    d0[:, 0, :, :5] -= 60.0                                       # columns whose windows lie left of the row
+    _, disp = stereo(left[:2], right[:2], iters=5, flow_init=d0)
+    lo_s, disp_ref = raft_ref.raft_stereo_forward(stereo, left[:2], right[:2], iters=5, flow_init=d0)
+    assert float(lo_s[:, 0].abs().max()) > 40.0
+    assert (disp - disp_ref).abs().mean().item() < 1e-3 and (disp - disp_ref).abs().max().item() < 0.05
+
+
+def test_plugins_load_module_prefixed_checkpoints(vo, tmp_path):
+    """The wrappers constructed from a checkpoint file saved the way the published models' are (every key prefixed
+    ``module.``: flow/flow_map_RAFT.py:42-47, stereo/stereo_disparity_RAFT.py:46-51) compute with those weights:
+    the same flow / disparity as the restated networks carrying the saved state dict."""
+    from oracle import raft_modules
+    from visual_odometry_amd import synthetic as syn
+    from visual_odometry_amd.raft.models import RAFTFlow, RAFTStereo, RAFTStereoConfig
+    from visual_odometry_amd.raft_plugins import HipDisparityRAFT, HipOpticalFlowRAFT
+    torch.manual_seed(33)
+    src_f, src_s = RAFTFlow().eval(), RAFTStereo(RAFTStereoConfig.realtime()).eval()
+    for m in list(src_f.modules()) + list(src_s.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):                    # a trained checkpoint's buffers are not the initial ones
+            m.running_mean.uniform_(-0.3, 0.3); m.running_var.uniform_(0.6, 1.6)
+    pf, ps = tmp_path / "raft_flow.pth", tmp_path / "raft_stereo.pth"
+    torch.save({"module." + k: v for k, v in src_f.state_dict().items()}, pf)
+    torch.save({"module." + k: v for k, v in src_s.state_dict().items()}, ps)
+    left, right = syn.stereo_sequence(5, 2, 128, 160)
+    fs = HipOpticalFlowRAFT(str(pf), None, iters=3, seed=99)       # the seed's random weights are overwritten by the file
+    ds = HipDisparityRAFT(str(ps), None, iters=3, config=RAFTStereoConfig.realtime(), seed=98)
+    for k, v in src_f.state_dict().items():
+        assert torch.equal(fs.model.state_dict()[k].cpu(), v), k
+    flow = fs.compute_flow(left[0], left[1])
+    disp = ds.compute_disparity(left[0], right[0])
+    rgb = lambda a: torch.from_numpy(np.repeat(a[None, None], 3, axis=1)).float().to(DEV)
+    _, f_ref = raft_modules.flow_twin(src_f, DEV)(rgb(left[0]), rgb(left[1]), 3)
+    _, d_ref = raft_modules.stereo_twin(src_s, DEV)(rgb(left[0]), rgb(right[0]), 3)
+    assert np.abs(flow - f_ref[0].cpu().numpy()).max() < 1e-3 and np.abs(disp - d_ref[0, 0].cpu().numpy()).max() < 1e-3
+    assert float(np.abs(flow).max()) > 1e-3
+
+
 def test_gray_stem_equals_three_equal_channels(vo):
     """Encoders fed the single plane of a gray frame (stem filter summed over its input channels) against
     the same encoders fed three equal channels: rounding-level differences only."""
