@@ -141,6 +141,12 @@ def mixed_precision_leg(vo32, vo16, left, right, cached, steps):
             "note": "not the reference's precision (mixed_precision=False there); reported beside, not as, the metric"}
 
 
+def progress(msg):
+    """One line on stderr per phase: a harness watching for a hung run sees the bench move (stdout stays one JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def _time(fn, repeat):
     fn()                                   # warm-up
     t0 = time.perf_counter()
@@ -177,7 +183,9 @@ def cpu_baseline(vo, left, right, iters, threads, stereo_name):
         _, disp = stereo_m(l[1:n + 1], r[1:n + 1], iters)
         t1 = time.perf_counter()
         _, flow = flow_m(l[:n], l[1:n + 1], iters)
-        return t1 - t0, time.perf_counter() - t1, disp, flow
+        t2 = time.perf_counter()
+        progress(f"cpu baseline: {n} pair(s), {torch.get_num_threads()} thread(s): stereo {t1 - t0:.1f}s, flow {t2 - t1:.1f}s")
+        return t1 - t0, t2 - t1, disp, flow
 
     torch.set_num_threads(threads)
     flow_m(small, small, 1)                                           # thread-pool / allocator warm-up
@@ -307,8 +315,10 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--mixed-precision", action="store_true",
                     help="time the float16-activation path as the headline instead of float32 (not the reference's precision)")
-    ap.add_argument("--no-mixed-precision-leg", action="store_true",
-                    help="skip the secondary float16-activation measurement")
+    ap.add_argument("--mixed-precision-leg", action="store_true",
+                    help="add the secondary float16-activation measurement (MIOpen's float16 kernels: about two minutes "
+                         "of solver set-up on a fresh machine; slower and less exact than the default arithmetic)")
+    ap.add_argument("--no-mixed-precision-leg", action="store_true", help="accepted for older scripts: that leg is off by default")
     ap.add_argument("--no-config-legs", action="store_true",
                     help="skip the secondary measurements of the reference's default (full) argument set")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the measurement with frames uploaded from pinned host memory")
@@ -391,6 +401,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    progress(f"{world} rank(s), {B} pairs per step: first chunk and {args.warmup} warm-up step(s)")
     # untimed: first chunk of the shard (computes the halo frame's depth too), then W warm-up steps
     _, _, cached = vo.process_chunk(left, right, None)
     for _ in range(args.warmup):
@@ -413,6 +424,7 @@ def main():
 
     pairs = world * B * args.steps
     value = pairs / elapsed
+    progress(f"timed {args.steps} step(s): {pairs / elapsed:.1f} frame-pairs/s")
 
     # outside the timed region: the one exchange of the sharded loop, an all-gather of the ranks'
     # relative poses (RCCL when launched by torch.distributed.run), then the host composition
@@ -541,6 +553,7 @@ def main():
             # the same step with the chunk's frames coming from pinned host memory, uploaded on a second
             # stream one chunk ahead of the computation (what a caller holding host frames pays)
             reps = max(2, min(args.steps, 4))
+            progress("leg: with_upload")
             lh = left.cpu().repeat(reps, 1, 1)[: reps * B + 1].pin_memory()
             rh = right.cpu().repeat(reps, 1, 1)[: reps * B + 1].pin_memory()
             vo.run(lh[: B + 1], rh[: B + 1], chunk_pairs=B)
@@ -564,6 +577,7 @@ def main():
             for kind, key in (("f32", "f32_mfma_only"), ("bf16x3", "bf16x3"), ("f16x3", "f16x3")):
                 if kind == args.conv_arithmetic:
                     continue
+                progress(f"leg: {key}")
                 vo.set_conv_arithmetic(kind)
                 try:
                     dt_k = timed_steps(vo, left, right, cached, max(1, min(args.steps, 3)), 1)
@@ -571,20 +585,24 @@ def main():
                     vo.set_conv_arithmetic(args.conv_arithmetic)
                 out[key] = {"value": B / dt_k, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt_k, "dtype": DTYPE_TEXT[kind],
                             "note": notes[kind]}
-        if world == 1 and not args.mixed_precision and not args.no_mixed_precision_leg:
+        if world == 1 and not args.mixed_precision and args.mixed_precision_leg and not args.no_mixed_precision_leg:
+            progress("leg: mixed_precision")
             out["mixed_precision"] = mixed_precision_leg(vo, make_vo(True), left, right, cached, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_cores or torch.get_num_threads()
+            progress(f"leg: cpu_baseline on {threads} thread(s)")
             out["cpu_baseline"] = cpu_baseline(vo, left, right, args.iters, threads, args.stereo)
         if world == 1 and not args.mixed_precision and not args.no_config_legs and args.stereo == "realtime":
             legs_steps = max(1, min(args.steps, 3))
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats()
             # BASELINE config 3: the argument set the reference hard-codes (stereo_disparity_RAFT.py:33-44)
+            progress("leg: full_args")
             out["full_args"] = config_leg(lambda: make_vo(False, "full", args.iters, "svd"), left, right, legs_steps,
                                           f"RAFT-Flow + RAFT-Stereo(full args: hidden 128x3, 3 GRU levels) {W}x{H}, "
                                           f"{args.iters} iters, Kabsch pose")
             # what test_camera_tracking.py:66-82 itself runs: full args, iters=16, CameraRansacXform(0.05, 1000)
+            progress("leg: reference_driver_settings")
             out["reference_driver_settings"] = config_leg(
                 lambda: make_vo(False, "full", 16, "ransac"), left, right, legs_steps,
                 f"RAFT-Flow + RAFT-Stereo(full args) {W}x{H}, 16 iters, RANSAC pose (1000 hypotheses per pair)")
@@ -596,6 +614,7 @@ def main():
             cfg_h = VOConfig(iters=args.iters, stereo=RAFTStereoConfig.realtime(), max_keypoints=20000,
                              camera_offset=syn.CAMERA_OFFSET)
             torch.cuda.reset_peak_memory_stats()
+            progress("leg: high_resolution")
             out["high_resolution"] = config_leg(
                 lambda: VisualOdometry(cfg_h, syn.left_K(2.0), syn.focal_length_px() * 2.0, syn.baseline(), np.ones((720, 1280), bool), seed=0),
                 lh, rh, legs_steps, f"RAFT-Flow + RAFT-Stereo(realtime args) 1280x720, {args.iters} iters, 19928 grid keypoints, Kabsch pose")
