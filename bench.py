@@ -349,6 +349,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the one JSON line and nothing else: whatever a library writes to file descriptor 1 (gloo announces
+    # its ranks there) goes to stderr from here on, the line itself through a duplicate of the original descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     # One rank per GPU over RCCL.  With fewer GPUs than local ranks (a rehearsal of the multi-rank path on a one-GPU
@@ -619,7 +624,7 @@ def main():
                 lambda: VisualOdometry(cfg_h, syn.left_K(2.0), syn.focal_length_px() * 2.0, syn.baseline(), np.ones((720, 1280), bool), seed=0),
                 lh, rh, legs_steps, f"RAFT-Flow + RAFT-Stereo(realtime args) 1280x720, {args.iters} iters, 19928 grid keypoints, Kabsch pose")
             del lh, rh
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
