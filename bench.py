@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec
+SUSTAINED_16BIT_TFLOPS = {"f16x3": 1560.0, "bf16x3": 1670.0}   # measured, random operands (power-limited clock)
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak
 # kernels whose float32 products are three bf16 matrix-core terms: their recorded FLOPs are the bf16
@@ -52,7 +53,8 @@ DTYPE_TEXT = {
              "many-channel 1x1 and 7x7 convolutions (GRU gate convolutions included) is three float16 matrix-core terms on "
              "operands cut into two float16 pieces: 22 significant bits per operand, exact power-of-two scaling for the "
              "exponent range, |x| > 65504 -> NaN; measured error of a layer = the float32 matrix instruction's; the "
-             "correlation volumes run on the float32 matrix instruction itself; see f32_mfma_only and bf16x3 beside it)",
+             "correlation volumes likewise, each image's feature map scaled by the power of two of its largest |x| before "
+             "the cut; see f32_mfma_only and bf16x3 beside it)",
     "bf16x3": "f32 tensors and accumulation; heavy products (convolutions and correlation volumes) from three bf16 "
               "matrix-core terms, 16 significant bits per operand: narrower than the reference's float32",
 }
@@ -487,6 +489,12 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": d["avg_us"]}
     AR = args.conv_arithmetic
+    if dom in SPLIT_BF16_KERNELS and AR in SUSTAINED_16BIT_TFLOPS:
+        # the nominal peak assumes 2.4 GHz; on operands that toggle the multipliers the chip holds far less (power limit)
+        roofline["sustained_peak_random_operands"] = SUSTAINED_16BIT_TFLOPS[AR]
+        roofline["frac_of_sustained"] = d["TFLOPs"] / SUSTAINED_16BIT_TFLOPS[AR]
+        roofline["sustained_peak_source"] = ("profiles/r03_power_limit.txt: the bare matrix instruction from registers on random "
+                                             "operands (tools/mfma_f16_vs_bf16.hip), committed with the repository")
     roofline["traffic"] = pmc_traffic(dom, B, H, W, AR)
     roofline["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload "
                                   "(tools/collect_profiles_r03.sh), committed with the repository, not measured in this run")
@@ -523,9 +531,13 @@ def main():
                          "float32_equivalent_TFLOPs": cp["TFLOPs"] / 3.0, "hbm_GBps": cp["GBps"],
                          "hbm_frac": cp["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic("vo_corr_volume_2d_presplit", B, H, W, AR),
                          "mfma_busy_pmc": mfma_util_from_profile("corr2d_presplit", B, H, W, AR),
-                         "note": "split-bf16 products (three bf16 matrix-core terms per float32 product) on feature rows split into "
-                                 "their bf16 pieces by the encoder's last layer; achieved counts the bf16 multiply-adds issued; "
-                                 "the float32-instruction kernel's figures are in the f32_mfma_only leg's run (--conv-arithmetic f32)"}
+                         "note": ("three float16 matrix-core terms per float32 product on feature rows cut into float16 pieces "
+                                  "beforehand (each image's map scaled by the power of two of its largest |x|: vo_feature_rows_amax + "
+                                  "vo_split_feature_rows, listed under kernels); achieved counts the 16-bit multiply-adds issued"
+                                  if AR == "f16x3" else
+                                  "three bf16 matrix-core terms per float32 product on feature rows split into their bf16 pieces by "
+                                  "the encoder's last layer; achieved counts the bf16 multiply-adds issued") +
+                                 "; the float32-instruction kernel's figures are in the f32_mfma_only leg's run (--conv-arithmetic f32)"}
     roofline["alg_per_launch"] = (work[dom].get("flops") if roofline["bound"] == "mfma" else work[dom]["bytes"]) / work[dom]["launches"]
     hand_ms = sum(k["ms_per_step"] for k in kernels.values())
 

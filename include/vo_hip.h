@@ -36,7 +36,7 @@ extern "C" {
  * VO_HIP_VERSION is the version this header describes: a caller compares vo_version() with it (or with the
  * value its own binding was written for) before the first call, because a library built from another header
  * would take shifted arguments without any error. */
-#define VO_HIP_VERSION 300
+#define VO_HIP_VERSION 301
 int vo_version(void);
 /* Message for the last non-zero status returned on this thread ("" if none). */
 const char* vo_last_error(void);
@@ -385,29 +385,48 @@ int vo_corr_volume_2d(const float* fmap1, const float* fmap2, float* corr,
                       int batch, int H, int W, int D, void* stream);
 int vo_corr_volume_1d(const float* fmap1, const float* fmap2, float* corr,
                       int batch, int H, int W1, int W2, int D, void* stream);
-/* The same two volumes with every float32 product assembled from three bf16 matrix-core terms
- * (al*bh + ah*bl + ah*bh, float32 accumulation: 16 significant bits per product, largest error about 5e-6 of
- * the largest entry; exact on small integers): the bf16 instruction runs at 16 times the float32 one's rate, so
- * the store of the volume becomes the bound.  These kernels (and the _presplit ones below) scale by the float32
- * value 1/sqrt(D) where vo_corr_volume_* divide by sqrt(D): the same bits when D is a power of 4 (D = 256, the
- * networks' width), one more rounding of 2^-24 otherwise -- far inside this arithmetic's 16 bits. */
+/* The same two volumes with every float32 product assembled from three 16-bit matrix-core terms
+ * (al*bh + ah*bl + ah*bh, float32 accumulation); the 16-bit instructions run at 16 times the float32 one's rate, so
+ * the store of the volume becomes the bound.
+ *   pieces = VO_PIECES_BF16: 16 significant bits per operand, largest error about 5e-6 of the largest entry, exact
+ *     on small integers; amax1 / amax2 are ignored (NULL).
+ *   pieces = VO_PIECES_F16: 22 significant bits per operand (the float32 instruction's error).  A feature map has no
+ *     known scale, so each IMAGE's map is multiplied by the power of two that puts its largest |x| into [2^13, 2^14)
+ *     before it is cut and the volume is multiplied by the inverse powers in the store (all exact).  amax1 / amax2
+ *     (device memory, `batch` entries each, float bits of the largest |x| of fmap1[b] / fmap2[b]) come from
+ *     vo_feature_rows_amax; the values never pass through the host.  Per image and not per launch, so a pair's volume
+ *     does not depend on the other pairs of its batch.  Multiplying a map by a power of two multiplies the volume by
+ *     it, bit for bit.
+ * These kernels (and the _presplit ones below) scale by the float32 value 1/sqrt(D) where vo_corr_volume_* divide by
+ * sqrt(D): the same bits when D is a power of 4 (D = 256, the networks' width), one more rounding of 2^-24
+ * otherwise. */
 int vo_corr_volume_2d_bf16x3(const float* fmap1, const float* fmap2, float* corr,
-                             int batch, int H, int W, int D, void* stream);
+                             int batch, int H, int W, int D, int pieces, const unsigned* amax1, const unsigned* amax2, void* stream);
 int vo_corr_volume_1d_bf16x3(const float* fmap1, const float* fmap2, float* corr,
-                             int batch, int H, int W1, int W2, int D, void* stream);
-/* ... and on feature maps whose rows were split into those bf16 pieces beforehand, once per map instead of once per
+                             int batch, int H, int W1, int W2, int D, int pieces, const unsigned* amax1, const unsigned* amax2,
+                             void* stream);
+/* amax[i] = float bits of the largest |x| among the elems_per_image values of image i (a multiple of 4; x 16-byte
+ * aligned; at most 65535 images); a NaN anywhere in an image makes its entry a NaN's bits.  Part of the same call
+ * sites' arithmetic, no counterpart of its own in the reference. */
+int vo_feature_rows_amax(const float* x, unsigned* amax, int images, int64_t elems_per_image, void* stream);
+/* ... and on feature maps whose rows were split into their pieces beforehand, once per map instead of once per
  * tile that reads the row (the call sites are the same: flow/flow_map_RAFT.py:81, stereo/stereo_disparity_RAFT.py:91).
  * vo_split_feature_rows turns `rows` rows of D float32 into the same 4*D bytes per row: per block of `block`
- * features (32 for the 2-D volume, 16 for the 1-D one; D a multiple of it), `block` high parts (bf16(x)) followed by
- * `block` low parts (bf16(x - high)); out must not alias x.  vo_conv1x1_split_rows_bf16x3 (above) writes the
- * block-32 form from a feature encoder's last layer directly.  Results equal vo_corr_volume_*_bf16x3 bit for bit.
+ * features (32 for the 2-D volume, 16 for the 1-D one; D a multiple of it), `block` high parts followed by
+ * `block` low parts; out must not alias x.  VO_PIECES_BF16: high = bf16(x), low = bf16(x - high), amax and
+ * rows_per_image ignored; vo_conv1x1_split_rows_bf16x3 (above) writes this block-32 form from a feature encoder's
+ * last layer directly.  VO_PIECES_F16: x' = x * 2^e(image), high = f16(x'), low = f16(x' - high), with amax from
+ * vo_feature_rows_amax over images of rows_per_image rows (rows a multiple of it).  Results equal
+ * vo_corr_volume_*_bf16x3 with the same pieces bit for bit.
  * The 2-D kernel: 256 x 256 tiles, one workgroup per CU walking a tile list, the next tile's first slices requested
  * before the finished tile is stored. */
-int vo_split_feature_rows(const float* x, void* out, int64_t rows, int D, int block, void* stream);
+int vo_split_feature_rows(const float* x, void* out, int64_t rows, int D, int block, int pieces, const unsigned* amax,
+                          int64_t rows_per_image, void* stream);
 int vo_corr_volume_2d_presplit(const void* fmap1, const void* fmap2, float* corr,
-                               int batch, int H, int W, int D, void* stream);
+                               int batch, int H, int W, int D, int pieces, const unsigned* amax1, const unsigned* amax2, void* stream);
 int vo_corr_volume_1d_presplit(const void* fmap1, const void* fmap2, float* corr,
-                               int batch, int H, int W1, int W2, int D, void* stream);
+                               int batch, int H, int W1, int W2, int D, int pieces, const unsigned* amax1, const unsigned* amax2,
+                               void* stream);
 
 /* ---------------------------------------------------------------------------
  * Correlation pyramid: levels 1..3 from level 0 in one pass (avg_pool 2x2 / 1x2,

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     lib = _lib.load()
     for n in names:
         assert getattr(lib, n) is not None
-    assert _lib.version() == _lib.ABI_VERSION == 300
+    assert _lib.version() == _lib.ABI_VERSION == 301
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

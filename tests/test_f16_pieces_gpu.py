@@ -236,3 +236,120 @@ def test_two_pipelines_in_one_process_keep_their_own_arithmetic(vo):
     assert not torch.equal(fa0, fb0)
     with pytest.raises(ValueError):
         make("int8")
+
+
+# ---------------------------------------------------------------------------------------------------
+# correlation volumes on float16 pieces (per-image power-of-two scaling from the largest |x|)
+
+def _amax_bits_host(x: torch.Tensor) -> torch.Tensor:
+    """Host statement of vo_feature_rows_amax: the float bits of each image's largest |x|."""
+    return x.abs().reshape(x.shape[0], -1).amax(dim=1).contiguous().view(torch.int32)
+
+
+def _feature_exp_host(bits: torch.Tensor) -> torch.Tensor:
+    E = (bits >> 23) & 0xff
+    e = torch.clamp(140 - E, max=120)
+    return torch.where((E == 0) | (E == 255), torch.zeros_like(e), e)
+
+
+def _split_rows_f16_host(x: torch.Tensor, block: int, bits: torch.Tensor) -> torch.Tensor:
+    """Host statement of the float16 split-row format: x' = x * 2^e(image), high = float16(x'), low =
+    float16(x' - high), per row and block ``block`` high parts then ``block`` low parts; int16 bits (..., 2*D)."""
+    e = _feature_exp_host(bits).view(-1, *([1] * (x.dim() - 1)))
+    xs = x * torch.exp2(e.float())
+    hi = xs.to(torch.float16)
+    lo = (xs - hi.float()).to(torch.float16)
+    D = x.shape[-1]
+    hb = hi.view(torch.int16).reshape(*x.shape[:-1], D // block, block)
+    lb = lo.view(torch.int16).reshape(*x.shape[:-1], D // block, block)
+    return torch.cat([hb, lb], dim=-1).reshape(*x.shape[:-1], 2 * D)
+
+
+@pytest.mark.parametrize("B,H,W,D", [(2, 12, 20, 256), (1, 7, 10, 64), (1, 9, 65, 256), (2, 60, 80, 256), (3, 33, 40, 128)])
+def test_corr_volume_2d_float16_pieces(vo, B, H, W, D):
+    """The flow volume on float16 pieces: the per-image maxima and the cut rows against their host statements (bit for
+    bit), the kernel that reads cut rows against the kernel that cuts inside (bit for bit), both against the float64
+    volume at the float32 instruction's own error, and no worse than twice the float32-instruction kernel."""
+    from visual_odometry_amd import ops
+    f1, f2 = _rand(B, H, W, D, seed=31).to(DEV), (_rand(B, H, W, D, seed=32) * 3.7).to(DEV)
+    a1, a2 = ops.feature_rows_amax(f1), ops.feature_rows_amax(f2)
+    assert torch.equal(a1.cpu(), _amax_bits_host(f1.cpu())) and torch.equal(a2.cpu(), _amax_bits_host(f2.cpu()))
+    s1, s2 = ops.split_feature_rows(f1, 32, "f16", a1), ops.split_feature_rows(f2, 32, "f16", a2)
+    assert torch.equal(s1.view(torch.int16).cpu(), _split_rows_f16_host(f1.cpu(), 32, a1.cpu()))
+    got = ops.corr_volume_2d_presplit(s1, s2, "f16", a1, a2)
+    assert torch.equal(got, ops.corr_volume_2d(f1, f2, split="f16"))
+    assert torch.equal(got, ops.corr_volume_2d(f1, f2, split="f16", amax1=a1, amax2=a2))
+    want = torch.einsum("bid,bjd->bij", f1.view(B, H * W, D).double(), f2.view(B, H * W, D).double()) / D ** 0.5
+    e16 = _err(got.view(B, H * W, H * W), want)
+    e32 = _err(ops.corr_volume_2d(f1, f2).view(B, H * W, H * W), want)
+    ebf = _err(ops.corr_volume_2d(f1, f2, split=True).view(B, H * W, H * W), want)
+    assert e16 < F32_GRADE_TOL and e16 < 2 * e32 + 2e-7, (e16, e32)
+    assert ebf > BF16_FLOOR > e16, (ebf, e16)
+
+
+def test_corr_volume_float16_pieces_scale_with_powers_of_two_and_per_image(vo):
+    """Multiplying a map by a power of two multiplies the volume by it bit for bit, from 2^-60 to 2^60 (the per-image
+    exponent absorbs it); a pair's volume does not depend on the other pairs of its launch; maps whose images differ in
+    scale by 10^6 keep the float32-grade error per image; small integers are exact; an all-zero map gives zeros and a
+    NaN in a map stays a NaN in its own image only."""
+    from visual_odometry_amd import ops
+    B, H, W, D = 3, 20, 24, 256
+    f1, f2 = _rand(B, H, W, D, seed=33).to(DEV), _rand(B, H, W, D, seed=34).to(DEV)
+    vol = ops.corr_volume_2d(f1, f2, split="f16")
+    for k1, k2 in ((7, -3), (-60, 60), (40, 20), (-50, -50)):
+        assert torch.equal(ops.corr_volume_2d(f1 * 2.0 ** k1, f2 * 2.0 ** k2, split="f16"), vol * 2.0 ** (k1 + k2)), (k1, k2)
+    assert torch.equal(ops.corr_volume_2d(f1[1:2].contiguous(), f2[1:2].contiguous(), split="f16"), vol[1:2])
+    scales = torch.tensor([1e-3, 1.0, 1e3], device=DEV).view(3, 1, 1, 1)
+    g = ops.corr_volume_2d(f1 * scales, f2, split="f16").view(B, H * W, H * W)
+    want = torch.einsum("bid,bjd->bij", (f1 * scales).view(B, H * W, D).double(), f2.view(B, H * W, D).double()) / 16.0
+    for b in range(B):
+        assert _err(g[b], want[b]) < F32_GRADE_TOL
+    gi = torch.Generator().manual_seed(35)
+    i1 = torch.randint(-3, 4, (1, 9, 65, 256), generator=gi).float()
+    i2 = torch.randint(-3, 4, (1, 9, 65, 256), generator=gi).float()
+    exact = (i1.view(585, 256).double() @ i2.view(585, 256).double().T / 16.0).float()
+    assert torch.equal(ops.corr_volume_2d(i1.to(DEV), i2.to(DEV), split="f16").cpu().view(585, 585), exact)
+    z = f1.clone(); z[0] = 0.0; z[2, 3, 4, 5] = float("nan")
+    vz = ops.corr_volume_2d(z, f2, split="f16")
+    assert torch.equal(vz[0], torch.zeros_like(vz[0])) and torch.equal(vz[1], vol[1])
+    assert torch.isnan(vz[2].view(H * W, H * W)[3 * W + 4]).all()
+
+
+@pytest.mark.parametrize("B,H,W1,W2,D", [(2, 6, 160, 160, 256), (1, 3, 40, 40, 256), (1, 2, 320, 320, 256), (2, 5, 50, 37, 64)])
+def test_corr_volume_1d_float16_pieces(vo, B, H, W1, W2, D):
+    """The per-row (stereo) volume on float16 pieces, one exponent per image shared by its rows: against float64, against
+    the kernel on rows cut beforehand (bit for bit), exact power-of-two scaling."""
+    from visual_odometry_amd import ops
+    f1, f2 = (_rand(B, H, W1, D, seed=36) * 0.05).to(DEV), _rand(B, H, W2, D, seed=37).to(DEV)
+    got = ops.corr_volume_1d(f1, f2, split="f16")
+    want = torch.einsum("bhid,bhjd->bhij", f1.double(), f2.double()) / D ** 0.5
+    e16, e32 = _err(got, want), _err(ops.corr_volume_1d(f1, f2), want)
+    assert got.shape == (B, H, W1, W2) and e16 < F32_GRADE_TOL and e16 < 2 * e32 + 2e-7, (e16, e32)
+    a1, a2 = ops.feature_rows_amax(f1), ops.feature_rows_amax(f2)
+    pre = ops.corr_volume_1d_presplit(ops.split_feature_rows(f1, 16, "f16", a1), ops.split_feature_rows(f2, 16, "f16", a2), "f16", a1, a2)
+    assert torch.equal(pre, got)
+    assert torch.equal(ops.corr_volume_1d(f1 * 1024.0, f2 * 2.0 ** -9, split="f16"), got * 2.0)
+    with pytest.raises(ValueError):
+        ops.corr_volume_1d_presplit(f1, f2, "f16")                       # cut rows without their maxima
+    with pytest.raises(ValueError):
+        ops.corr_volume_1d(f1, f2, split="fp8")
+
+
+def test_flow_volume_of_consecutive_pairs_cuts_each_frame_once(vo):
+    """raft.models._flow_volume_f16 on the maps of a sequence (maps[:-1], maps[1:], views of one buffer) cuts the B+1
+    frames once; the volume equals the one from two separate tensors bit for bit."""
+    from visual_odometry_amd import ops
+    from visual_odometry_amd.raft import models
+    maps = _rand(5, 12, 20, 256, seed=38).to(DEV)
+    rec = {}
+    old = ops.set_recorder(rec)
+    try:
+        got = models._flow_volume_f16(maps[:-1], maps[1:])
+    finally:
+        ops.set_recorder(old)
+    assert len(rec["vo_feature_rows_amax"]) == 1 and len(rec["vo_split_feature_rows"]) == 1
+    a, b = maps[:-1].clone(), maps[1:].clone()
+    assert torch.equal(got, models._flow_volume_f16(a, b))
+    assert torch.equal(got, ops.corr_volume_2d(a, b, split="f16"))
+    # a view that ends at the buffer's end must not be extended past it
+    assert torch.equal(models._flow_volume_f16(maps[:4], maps[:4]), ops.corr_volume_2d(maps[:4].contiguous(), maps[:4].contiguous(), split="f16"))

@@ -1292,8 +1292,11 @@ def test_networks_agree_across_conv_arithmetic(vo):
         # the kernels that ran are the arithmetic's own
         assert ("vo_conv3x3_winograd4" in rec) == (kind == "f32")
         assert ("vo_conv3x3_bf16x3" in rec) == (kind != "f32")
-        assert ("vo_corr_volume_2d_presplit" in rec) == (kind == "bf16x3")
-        assert ("vo_corr_volume_2d" in rec) == (kind != "bf16x3")
+        # the flow volume: cut rows (bf16 by the encoder's store, float16 by a pass behind the per-image maxima) or float32
+        assert ("vo_corr_volume_2d_presplit" in rec) == (kind != "f32")
+        assert ("vo_corr_volume_2d" in rec) == (kind == "f32")
+        assert ("vo_feature_rows_amax" in rec) == (kind == "f16x3")
+        assert ("vo_corr_volume_1d_bf16x3" in rec) == (kind != "f32")
     with pytest.raises(ValueError):
         flow.conv_arithmetic = "fp8"
         flow(left[:1], left[1:2], iters=1)

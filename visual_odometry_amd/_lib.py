@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libvo_hip.so")
 
 VO_OK, VO_ERR_INVALID_ARG, VO_ERR_LAUNCH, VO_ERR_UNSUPPORTED = 0, -1, -2, -3
-ABI_VERSION = 300           # the VO_HIP_VERSION of include/vo_hip.h that SIGNATURES below was written for
+ABI_VERSION = 301           # the VO_HIP_VERSION of include/vo_hip.h that SIGNATURES below was written for
 VO_PIECES_BF16, VO_PIECES_F16 = 0, 1
 
 _P, _I, _L, _D, _F = c_void_p, c_int, c_int64, c_double, c_float
@@ -66,11 +66,12 @@ SIGNATURES = {
     "vo_prepare_images_gray": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vo_corr_volume_2d": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vo_corr_volume_1d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vo_corr_volume_2d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "vo_corr_volume_1d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vo_split_feature_rows": [_P, _P, _L, _I, _I, _P],
-    "vo_corr_volume_2d_presplit": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "vo_corr_volume_1d_presplit": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vo_corr_volume_2d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "vo_corr_volume_1d_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "vo_feature_rows_amax": [_P, _P, _I, _L, _P],
+    "vo_split_feature_rows": [_P, _P, _L, _I, _I, _I, _P, _L, _P],
+    "vo_corr_volume_2d_presplit": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "vo_corr_volume_1d_presplit": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "vo_corr_pyramid_2d": [_P, _P, _P, _P, _L, _I, _I, _P],
     "vo_corr_pyramid_1d": [_P, _P, _P, _P, _L, _I, _P],
     "vo_corr_lookup_2d": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -27,6 +27,21 @@ static inline hipStream_t vo_stream(void* s) { return reinterpret_cast<hipStream
 
 static inline int64_t vo_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Small counters and maxima are zeroed by a kernel of their own, not by hipMemsetAsync: recorded into a HIP graph the
+// memset of a few words did not take effect in stream order on replay (a captured step replayed on new frames kept
+// the previous replay's values; tests/test_pipeline_gpu.py::test_a_step_captures_into_a_hip_graph), a kernel node does.
+namespace {
+__global__ void vo_zero_words_kernel(unsigned* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+}  // namespace
+static inline hipError_t vo_zero_words(void* p, int64_t words, hipStream_t st) {
+    if (words <= 0) return hipSuccess;
+    vo_zero_words_kernel<<<dim3((unsigned)vo_ceil_div(words, 256)), dim3(256), 0, st>>>(static_cast<unsigned*>(p), words);
+    return hipGetLastError();
+}
+
 constexpr int VO_WAVE = 64;   // CDNA4 wavefront width
 
 // Activation storage of the fused conv-net passes is float32 or float16 (VO_F32 /

@@ -337,8 +337,8 @@ extern "C" int vo_pair_correspondences(const double* kp, int64_t kp_batch_stride
     VO_REQUIRE(n_in_range_out, "vo_pair_correspondences: n_in_range_out is null");
     VO_REQUIRE(N == 0 || (depth1 && depth2 && flow && Kinv_host && p1_out && p2_out && weight_out),
                "vo_pair_correspondences: null pointer");
-    hipError_t e = hipMemsetAsync(n_in_range_out, 0, sizeof(int32_t) * (size_t)batch, vo_stream(stream));
-    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "vo_pair_correspondences: memset: %s", hipGetErrorString(e));
+    hipError_t e = vo_zero_words(n_in_range_out, batch, vo_stream(stream));
+    if (e != hipSuccess) return vo_fail(VO_ERR_LAUNCH, "vo_pair_correspondences: zeroing the counters: %s", hipGetErrorString(e));
     if (N == 0) return VO_OK;
     dim3 grid((unsigned)vo_ceil_div(N, 256), (unsigned)batch);
     flow3d_kernel<1><<<grid, dim3(256), 0, vo_stream(stream)>>>(kp, kp_batch_stride, depth1, depth2, flow,

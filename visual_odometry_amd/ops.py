@@ -872,62 +872,126 @@ def pyramid_shapes_2d(h2: int, w2: int, levels: int = MAX_LEVELS):
     return out
 
 
-def corr_volume_2d(fmap1: torch.Tensor, fmap2: torch.Tensor, split: bool = False) -> torch.Tensor:
+def _split_pieces(split) -> str | None:
+    """The correlation functions' ``split`` argument: False -> float32 matrix instructions (None), True or "bf16" ->
+    bf16 pieces, "f16" -> float16 pieces."""
+    if split is False or split is None:
+        return None
+    if split is True:
+        return "bf16"
+    if split in PIECES:
+        return split
+    raise ValueError(f"split must be False, True, 'bf16' or 'f16', got {split!r}")
+
+
+def feature_rows_amax(fmap: torch.Tensor) -> torch.Tensor:
+    """(B, ..., D) float32 feature maps -> (B,) int32: the float BITS of each image's largest |x|, what the
+    float16-piece correlation kernels take their per-image power of two from (it stays on the device)."""
+    B = fmap.shape[0]
+    amax = torch.empty((B,), device=fmap.device, dtype=torch.int32)
+    _call("vo_feature_rows_amax", _dev(fmap, "fmap", torch.float32), amax.data_ptr(), B, fmap.numel() // B, _stream(),
+          nbytes=fmap.numel() * 4)
+    return amax
+
+
+def _amax_ptrs(pieces, fmap1, fmap2, amax1, amax2):
+    if pieces != "f16":
+        return None, None, None, None
+    amax1 = feature_rows_amax(fmap1) if amax1 is None else amax1
+    amax2 = feature_rows_amax(fmap2) if amax2 is None else amax2
+    for a, f in ((amax1, fmap1), (amax2, fmap2)):
+        if a.dtype != torch.int32 or a.numel() != f.shape[0] or not a.is_contiguous() or a.device != f.device:
+            raise ValueError("amax must be a contiguous int32 tensor with one entry per image (feature_rows_amax)")
+    return amax1, amax2, amax1.data_ptr(), amax2.data_ptr()
+
+
+def corr_volume_2d(fmap1: torch.Tensor, fmap2: torch.Tensor, split=False, amax1=None, amax2=None) -> torch.Tensor:
     """All-pairs correlation of two pixel-major feature maps (B,H,W,D) ->
-    (B, H*W, H, W) float32, scaled by 1/sqrt(D).  ``split``: every float32 product from three bf16
-    matrix-core terms (16 significant bits) instead of the float32 matrix instruction."""
+    (B, H*W, H, W) float32, scaled by 1/sqrt(D).  ``split``: every float32 product from three 16-bit
+    matrix-core terms instead of the float32 matrix instruction: True / "bf16" (16 significant bits per
+    operand) or "f16" (22 bits; each image's map scaled by a power of two taken from its largest |x|:
+    ``amax1`` / ``amax2`` from feature_rows_amax, computed here when absent)."""
     B, H, W, D = fmap1.shape
     if fmap2.shape != fmap1.shape:
         raise ValueError("fmap1 and fmap2 must have the same shape")
+    pieces = _split_pieces(split)
     corr = torch.empty((B, H * W, H, W), device=fmap1.device, dtype=torch.float32)
-    _call("vo_corr_volume_2d_bf16x3" if split else "vo_corr_volume_2d", _dev(fmap1, "fmap1", torch.float32),
-          _dev(fmap2, "fmap2", torch.float32), corr.data_ptr(), B, H, W, D, _stream())
+    if pieces is None:
+        _call("vo_corr_volume_2d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+              corr.data_ptr(), B, H, W, D, _stream())
+        return corr
+    a1, a2, p1, p2 = _amax_ptrs(pieces, fmap1, fmap2, amax1, amax2)
+    _call("vo_corr_volume_2d_bf16x3", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+          corr.data_ptr(), B, H, W, D, PIECES[pieces], p1, p2, _stream())
     return corr
 
 
-def corr_volume_1d(fmap1: torch.Tensor, fmap2: torch.Tensor, split: bool = False) -> torch.Tensor:
+def corr_volume_1d(fmap1: torch.Tensor, fmap2: torch.Tensor, split=False, amax1=None, amax2=None) -> torch.Tensor:
     """Per-row all-pairs correlation (B,H,W1,D) x (B,H,W2,D) -> (B,H,W1,W2); ``split`` as corr_volume_2d."""
     B, H, W1, D = fmap1.shape
     if fmap2.shape[0] != B or fmap2.shape[1] != H or fmap2.shape[3] != D:
         raise ValueError("fmap2 must be (B,H,W2,D) matching fmap1")
     W2 = fmap2.shape[2]
+    pieces = _split_pieces(split)
     corr = torch.empty((B, H, W1, W2), device=fmap1.device, dtype=torch.float32)
-    _call("vo_corr_volume_1d_bf16x3" if split else "vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32),
-          _dev(fmap2, "fmap2", torch.float32), corr.data_ptr(), B, H, W1, W2, D, _stream())
+    if pieces is None:
+        _call("vo_corr_volume_1d", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+              corr.data_ptr(), B, H, W1, W2, D, _stream())
+        return corr
+    a1, a2, p1, p2 = _amax_ptrs(pieces, fmap1, fmap2, amax1, amax2)
+    _call("vo_corr_volume_1d_bf16x3", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
+          corr.data_ptr(), B, H, W1, W2, D, PIECES[pieces], p1, p2, _stream())
     return corr
 
 
-def split_feature_rows(fmap: torch.Tensor, block: int) -> torch.Tensor:
-    """Pixel-major feature maps (..., D) float32 -> a tensor of the same shape and dtype whose BYTES are the
-    maps' bf16 pieces: per row and block of ``block`` features, ``block`` high parts then ``block`` low
-    parts (high = bf16(x), low = bf16(x - high)).  What the ``presplit`` correlation kernels read: 32 for
-    corr_volume_2d_presplit, 16 for corr_volume_1d_presplit.  The values are not float32 numbers any more."""
+def split_feature_rows(fmap: torch.Tensor, block: int, pieces: str = "bf16", amax: torch.Tensor | None = None) -> torch.Tensor:
+    """Pixel-major feature maps (B, ..., D) float32 -> a tensor of the same shape and dtype whose BYTES are the
+    maps' 16-bit pieces: per row and block of ``block`` features, ``block`` high parts then ``block`` low
+    parts.  "bf16": high = bf16(x), low = bf16(x - high).  "f16": the same on x * 2^e with float16 parts, e per image
+    from ``amax`` (feature_rows_amax(fmap): pass the same tensor to the correlation call).  What the ``presplit``
+    correlation kernels read: 32 for corr_volume_2d_presplit, 16 for corr_volume_1d_presplit.  The values are not
+    float32 numbers any more."""
     D = fmap.shape[-1]
     out = torch.empty_like(fmap)
-    _call("vo_split_feature_rows", _dev(fmap, "fmap", torch.float32), out.data_ptr(), fmap.numel() // D, D, block, _stream())
+    rows = fmap.numel() // D
+    if pieces == "f16":
+        if amax is None or amax.dtype != torch.int32 or amax.numel() != fmap.shape[0] or not amax.is_contiguous():
+            raise ValueError("float16 pieces need amax = feature_rows_amax(fmap)")
+        _call("vo_split_feature_rows", _dev(fmap, "fmap", torch.float32), out.data_ptr(), rows, D, block, PIECES[pieces],
+              amax.data_ptr(), rows // fmap.shape[0], _stream(), nbytes=fmap.numel() * 8)
+    else:
+        _call("vo_split_feature_rows", _dev(fmap, "fmap", torch.float32), out.data_ptr(), rows, D, block, PIECES[pieces], None, 0, _stream(),
+              nbytes=fmap.numel() * 8)
     return out
 
 
-def corr_volume_2d_presplit(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
-    """corr_volume_2d(split=True) on feature maps already in split_feature_rows(., 32) form."""
+def corr_volume_2d_presplit(fmap1: torch.Tensor, fmap2: torch.Tensor, pieces: str = "bf16", amax1=None, amax2=None) -> torch.Tensor:
+    """corr_volume_2d(split=pieces) on feature maps already in split_feature_rows(., 32, pieces) form; float16
+    pieces with the ``amax`` entries of the two maps' images."""
     B, H, W, D = fmap1.shape
     if fmap2.shape != fmap1.shape:
         raise ValueError("fmap1 and fmap2 must have the same shape")
+    if pieces == "f16" and (amax1 is None or amax2 is None):
+        raise ValueError("float16 pieces need the amax entries the maps were split with")
+    a1, a2, p1, p2 = _amax_ptrs(pieces, fmap1, fmap2, amax1, amax2)
     corr = torch.empty((B, H * W, H, W), device=fmap1.device, dtype=torch.float32)
     _call("vo_corr_volume_2d_presplit", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
-          corr.data_ptr(), B, H, W, D, _stream())
+          corr.data_ptr(), B, H, W, D, PIECES[pieces], p1, p2, _stream())
     return corr
 
 
-def corr_volume_1d_presplit(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
-    """corr_volume_1d(split=True) on feature maps already in split_feature_rows(., 16) form."""
+def corr_volume_1d_presplit(fmap1: torch.Tensor, fmap2: torch.Tensor, pieces: str = "bf16", amax1=None, amax2=None) -> torch.Tensor:
+    """corr_volume_1d(split=pieces) on feature maps already in split_feature_rows(., 16, pieces) form."""
     B, H, W1, D = fmap1.shape
     if fmap2.shape[0] != B or fmap2.shape[1] != H or fmap2.shape[3] != D:
         raise ValueError("fmap2 must be (B,H,W2,D) matching fmap1")
+    if pieces == "f16" and (amax1 is None or amax2 is None):
+        raise ValueError("float16 pieces need the amax entries the maps were split with")
     W2 = fmap2.shape[2]
+    a1, a2, p1, p2 = _amax_ptrs(pieces, fmap1, fmap2, amax1, amax2)
     corr = torch.empty((B, H, W1, W2), device=fmap1.device, dtype=torch.float32)
     _call("vo_corr_volume_1d_presplit", _dev(fmap1, "fmap1", torch.float32), _dev(fmap2, "fmap2", torch.float32),
-          corr.data_ptr(), B, H, W1, W2, D, _stream())
+          corr.data_ptr(), B, H, W1, W2, D, PIECES[pieces], p1, p2, _stream())
     return corr
 
 

@@ -37,7 +37,8 @@ class Arithmetic:
                        "f16x3"   three float16 matrix-core terms per product, x*w ~ xl*wh + xh*wl + xh*wh with both
                                  operands cut into two float16 pieces: 22 significant bits per operand, float32
                                  accumulation; the error of a layer is that of the float32 matrix instruction.  The
-                                 correlation volumes run on the float32 matrix instruction itself.
+                                 correlation volumes likewise, every image's feature map scaled by the power of two
+                                 of its largest |x| before it is cut (found on the device, per image).
                        "bf16x3"  the same with bf16 pieces: 16 significant bits per operand, largest error 4-6e-6 of a
                                  layer's largest output; correlation volumes included.
                        "f32"     float32 matrix instructions only (Winograd kernels for 3x3 and 1x5 / 5x1; the

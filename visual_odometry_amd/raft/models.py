@@ -61,6 +61,25 @@ def load_checkpoint(model: nn.Module, path: str, device) -> None:
 
 # --------------------------------------------------------------------------- flow
 
+def _flow_volume_f16(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+    """The flow volume on float16 pieces: every image's map is scaled by its own power of two, cut once
+    (ops.split_feature_rows) and multiplied by the kernel that reads cut rows.  When fmap2 is fmap1 shifted by one
+    frame inside one buffer (consecutive pairs of a sequence: maps[:-1], maps[1:]) the B+1 distinct maps are cut
+    once instead of 2B."""
+    B = fmap1.shape[0]
+    fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+    per_frame = fmap1[0].numel()
+    if (fmap2.data_ptr() == fmap1.data_ptr() + per_frame * 4 and fmap1.untyped_storage().data_ptr() == fmap2.untyped_storage().data_ptr()
+            and fmap1.storage_offset() + (B + 1) * per_frame <= fmap1.untyped_storage().nbytes() // 4):
+        maps = torch.as_strided(fmap1, (B + 1,) + tuple(fmap1.shape[1:]), fmap1.stride())
+        amax = ops.feature_rows_amax(maps)
+        cut = ops.split_feature_rows(maps, 32, "f16", amax)
+        return ops.corr_volume_2d_presplit(cut[:B], cut[1:], "f16", amax[:B], amax[1:])
+    a1, a2 = ops.feature_rows_amax(fmap1), ops.feature_rows_amax(fmap2)
+    return ops.corr_volume_2d_presplit(ops.split_feature_rows(fmap1, 32, "f16", a1), ops.split_feature_rows(fmap2, 32, "f16", a2),
+                                       "f16", a1, a2)
+
+
 @dataclass
 class RAFTFlowConfig:
     corr_levels: int = 4
@@ -125,6 +144,8 @@ class RAFTFlow(nn.Module):
         # was measured slower and heavier on the memory counters for the lookup's gathers (tools/tiled_volume.hip.txt)
         if self.presplit_features():
             corr = ops.corr_volume_2d_presplit(fmap1.contiguous(), fmap2.contiguous())
+        elif self.conv_arithmetic == "f16x3" and fmap1.dtype == torch.float32 and fmap1.shape[-1] % 64 == 0:
+            corr = _flow_volume_f16(fmap1, fmap2)
         else:
             corr = ops.corr_volume_2d(fmap1, fmap2, split=self.conv_arithmetic == "bf16x3")
         pyramid = ops.corr_pyramid_2d(corr, c.corr_levels)
@@ -222,7 +243,11 @@ class RAFTStereo(nn.Module):
                         for i, conv in zip(inp_list, self.context_zqr_convs)]
         fmap1, fmap2 = both[:B], both[B:]
 
-        corr = ops.corr_volume_1d(fmap1, fmap2, split=self.conv_arithmetic == "bf16x3")
+        if self.conv_arithmetic == "f16x3" and both.dtype == torch.float32:
+            amax = ops.feature_rows_amax(both)                   # per image, stays on the device
+            corr = ops.corr_volume_1d(fmap1, fmap2, split="f16", amax1=amax[:B], amax2=amax[B:])
+        else:
+            corr = ops.corr_volume_1d(fmap1, fmap2, split=self.conv_arithmetic == "bf16x3")
         pyramid = ops.corr_pyramid_1d(corr, c.corr_levels)
 
         _, _, h, w = net_list[0].shape
