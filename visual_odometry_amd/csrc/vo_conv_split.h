@@ -121,6 +121,33 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // that stages the input a second time.  `sc` holds its weights (vo_conv1x1_bf16x3_filter), output and epilogue.
 struct Shortcut { const unsigned short* Ag; float* y; Epilogue ep; };
 
+// VO_CONV_TIMELINE (tools/conv_timeline.hip only): every workgroup leaves five stamps of the chip-wide 100 MHz counter
+// -- entry, first multiplication, end of the main loop, last store issued, stores complete -- and where it ran.
+#ifdef VO_CONV_TIMELINE                      // the including file defines __device__ unsigned long long vo_conv_timeline[] first
+struct ConvTimeline {
+    unsigned long long t[5];
+    __device__ __forceinline__ void stamp(int i) { t[i] = __builtin_amdgcn_s_memrealtime(); }
+    __device__ ~ConvTimeline() {
+        stamp(3);
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp(4);
+        if (threadIdx.x == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = vo_conv_timeline + (size_t)blockIdx.x * 6;
+            for (int i = 0; i < 5; ++i) o[i] = t[i];
+            o[5] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+};
+#define VO_TL_DECL ConvTimeline tl_; tl_.stamp(0)
+#define VO_TL(i) tl_.stamp(i)
+#else
+#define VO_TL_DECL
+#define VO_TL(i)
+#endif
+
 template <typename P, typename G, bool NORM_IN, int MT, bool GRU = false, bool SHORT = false>
 __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restrict__ x, const unsigned short* __restrict__ Ag,
                                                             float* __restrict__ y, Epilogue ep, InputNorm in, int C, int H,
@@ -137,6 +164,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     double* red = reinterpret_cast<double*>(lds);                            // [2][4 waves][64]
     static_assert(4 * PLANE >= 4 * 4096, "the epilogue's transposition slots and the reduction buffer do not fit the patch area");
 
+    VO_TL_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid;
     {   // one contiguous range of the block list per XCD (workgroups are dealt round robin over 8)
@@ -309,6 +337,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 *reinterpret_cast<u32x4*>(lds + 4 * PLANE + (tid + i * NT) * 16) = aw[i];
         if (SHORT) *reinterpret_cast<u32x4*>(a2_lds + tid * 16) = aw2;
         __syncthreads();
+        if (chunk == 0) { VO_TL(1); }
         load_raw(chunk + 1);                                                 // in flight during the whole multiply phase
 
         // STEPS steps of (tap, pixel tile): 3*MT matrix instructions each, operands double-buffered in
@@ -366,6 +395,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         load_aw(chunk + 1);
         __syncthreads();                                                     // everyone has read the patch and the weights
     }
+    VO_TL(2);
 
     if constexpr (P::F16) {
         // back to the weights' own scale (a power of two: exact)
