@@ -13,7 +13,7 @@ import re
 names = {"conv3x3_bf16x3": r"Geo<3, 3, 1, 4, (32|16)>, (true|false), [12], false, false>", "conv5_bf16x3": r"Geo<(1, 5|5, 1), 1, 4, (32|16)>, (true|false), [12], false, false>",
          "gru_conv_bf16x3": r"Geo<.*>, false, 2, true, false>", "conv3x3s2_bf16x3": r"Geo<3, 3, 2", "conv1x1s2_bf16x3": r"Geo<1, 1, 2",
          "conv1x1_bf16x3": r"Geo<1, 1, 1|conv1x1_stream_kernel", "conv7x7_bf16x3": r"conv7_split_kernel", "corr2d": r"corr_abt_kernel<128, 128, 32, 2, 2, false", "corr2d_bf16x3": r"corr_abt_kernel<128, 128, 32, 2, 2, true",
-         "corr1d": r"corr_abt_kernel<160, 160, 16, 1, 5, false", "corr1d_bf16x3": r"corr_abt_kernel<160, 160, 16, 1, 5, true", "corr2d_presplit": r"corr_presplit_big_kernel", "pyr2d": r"pyramid2d", "pyr1d": r"pyramid1d", "lookup2d": r"lookup2d", "lookup1d": r"lookup1d",
+         "corr1d": r"corr_abt_kernel<160, 160, 16, 1, 5, false", "corr1d_bf16x3": r"corr_abt_kernel<160, 160, 16, 1, 5, true", "corr2d_presplit": r"corr_presplit_big_kernel", "rows_amax": r"rows_amax_kernel", "split_rows": r"split_rows_kernel", "pyr2d": r"pyramid2d", "pyr1d": r"pyramid1d", "lookup2d": r"lookup2d", "lookup1d": r"lookup1d",
          "instnorm_apply": r"instnorm_apply_kernel", "conv1x1": r"conv1x1_kernel"}
 
 
