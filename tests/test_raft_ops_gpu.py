@@ -153,8 +153,16 @@ def test_correlation_chain_properties_at_full_size(vo):
     vol = ops.corr_volume_2d_presplit(s1, s2)
     assert torch.equal(vol, ops.corr_volume_2d(f1, f2, split=True))
     assert torch.equal(ops.corr_volume_2d_presplit(ops.split_feature_rows(f1 * 4.0, 32), s2), vol * 4.0)
-    swapped = ops.corr_volume_2d_presplit(s2, s1).view(B, N, N).transpose(1, 2)
+    # the float16-piece flavour (the default arithmetic's): rows cut beforehand = cut inside, power-of-two scaling exact,
+    # within float32 rounding of the bf16-piece volume's neighbourhood (5e-6) and of the float32-instruction volume (1e-6)
+    a1, a2 = ops.feature_rows_amax(f1), ops.feature_rows_amax(f2)
+    v16 = ops.corr_volume_2d_presplit(ops.split_feature_rows(f1, 32, "f16", a1), ops.split_feature_rows(f2, 32, "f16", a2), "f16", a1, a2)
+    assert torch.equal(v16, ops.corr_volume_2d(f1, f2, split="f16"))
+    assert torch.equal(ops.corr_volume_2d(f1 * 0.125, f2 * 64.0, split="f16"), v16 * 8.0)
     top = vol.abs().max().item()
+    assert (v16 - ops.corr_volume_2d(f1, f2)).abs().max().item() < 1.5e-6 * top and (v16 - vol).abs().max().item() < 1e-5 * top
+    del v16
+    swapped = ops.corr_volume_2d_presplit(s2, s1).view(B, N, N).transpose(1, 2)
     assert (swapped - vol.view(B, N, N)).abs().max().item() < 2e-6 * top
     del swapped
     pyr = ops.corr_pyramid_2d(vol, 4)
