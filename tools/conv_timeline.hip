@@ -14,7 +14,7 @@
 #include <vector>
 
 #define VO_CONV_TIMELINE
-__device__ unsigned long long vo_conv_timeline[6 * (1 << 20)];
+__device__ unsigned long long vo_conv_timeline[10 * (1 << 20)];
 #include "../visual_odometry_amd/csrc/vo_conv_split.h"
 
 int vo_fail(int code, const char* fmt, ...) {
@@ -52,8 +52,15 @@ int main(int argc, char** argv) {
     const int bx = (W + 31) / 32, by = (H + 15) / 16;                         // either geometry has 512-pixel tiles
     const size_t nwg = (size_t)((W + 31) / 32) * ((H + 15) / 16) * N * ((K + 63) / 64);
     (void)bx; (void)by;
-    std::vector<unsigned long long> tl(nwg * 6);
-    hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(vo_conv_timeline), nwg * 6 * 8);
+    std::vector<unsigned long long> tl10(nwg * 10), tl(nwg * 6);
+    hipMemcpyFromSymbol(tl10.data(), HIP_SYMBOL(vo_conv_timeline), nwg * 10 * 8);
+    double cseg[3] = {0, 0, 0};
+    for (size_t i = 0; i < nwg; ++i) {
+        for (int j = 0; j < 6; ++j) tl[i * 6 + j] = tl10[i * 10 + j];
+        for (int j = 0; j < 3; ++j) cseg[j] += (double)(tl10[i * 10 + 7 + j] - tl10[i * 10 + 6 + j]);
+    }
+    printf("second chunk, core clocks (mean): staging %.0f, multiply phase %.0f (216 matrix instructions = 6912), weights request + closing barrier %.0f\n",
+           cseg[0] / nwg, cseg[1] / nwg, cseg[2] / nwg);
     unsigned long long t_min = ~0ull, t_max = 0;
     for (size_t i = 0; i < nwg; ++i) { t_min = std::min(t_min, tl[i * 6]); t_max = std::max(t_max, tl[i * 6 + 4]); }
     const double tick_us = 0.01;

@@ -121,12 +121,14 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // that stages the input a second time.  `sc` holds its weights (vo_conv1x1_bf16x3_filter), output and epilogue.
 struct Shortcut { const unsigned short* Ag; float* y; Epilogue ep; };
 
+
 // VO_CONV_TIMELINE (tools/conv_timeline.hip only): every workgroup leaves five stamps of the chip-wide 100 MHz counter
 // -- entry, first multiplication, end of the main loop, last store issued, stores complete -- and where it ran.
 #ifdef VO_CONV_TIMELINE                      // the including file defines __device__ unsigned long long vo_conv_timeline[] first
 struct ConvTimeline {
-    unsigned long long t[5];
+    unsigned long long t[5], c[4] = {0, 0, 0, 0};                          // c: core-clock stamps inside the second chunk
     __device__ __forceinline__ void stamp(int i) { t[i] = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void cycles(int i) { c[i] = __builtin_readcyclecounter(); }
     __device__ ~ConvTimeline() {
         stamp(3);
         __builtin_amdgcn_s_waitcnt(0);
@@ -135,17 +137,20 @@ struct ConvTimeline {
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* o = vo_conv_timeline + (size_t)blockIdx.x * 6;
+            unsigned long long* o = vo_conv_timeline + (size_t)blockIdx.x * 10;
             for (int i = 0; i < 5; ++i) o[i] = t[i];
             o[5] = ((unsigned long long)xcc << 32) | hw;
+            for (int i = 0; i < 4; ++i) o[6 + i] = c[i];
         }
     }
 };
 #define VO_TL_DECL ConvTimeline tl_; tl_.stamp(0)
 #define VO_TL(i) tl_.stamp(i)
+#define VO_TLC(i) tl_.cycles(i)
 #else
 #define VO_TL_DECL
 #define VO_TL(i)
+#define VO_TLC(i)
 #endif
 
 template <typename P, typename G, bool NORM_IN, int MT, bool GRU = false, bool SHORT = false>
@@ -330,6 +335,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
     load_aw(0);
     if (NORM_IN) __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk == 1) { VO_TLC(0); }
         store_raw(chunk);
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i)
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
         if (SHORT) *reinterpret_cast<u32x4*>(a2_lds + tid * 16) = aw2;
         __syncthreads();
         if (chunk == 0) { VO_TL(1); }
+        if (chunk == 1) { VO_TLC(1); }
         load_raw(chunk + 1);                                                 // in flight during the whole multiply phase
 
         // STEPS steps of (tap, pixel tile): 3*MT matrix instructions each, operands double-buffered in
@@ -392,8 +399,10 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(const float* __restr
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (chunk == 1) { VO_TLC(2); }
         load_aw(chunk + 1);
         __syncthreads();                                                     // everyone has read the patch and the weights
+        if (chunk == 1) { VO_TLC(3); }
     }
     VO_TL(2);
 
