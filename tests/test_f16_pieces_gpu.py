@@ -353,3 +353,29 @@ def test_flow_volume_of_consecutive_pairs_cuts_each_frame_once(vo):
     assert torch.equal(got, ops.corr_volume_2d(a, b, split="f16"))
     # a view that ends at the buffer's end must not be extended past it
     assert torch.equal(models._flow_volume_f16(maps[:4], maps[:4]), ops.corr_volume_2d(maps[:4].contiguous(), maps[:4].contiguous(), split="f16"))
+
+
+def test_corr_volume_float16_pieces_over_odd_shapes(vo):
+    """Seeded random shapes that leave the fast paths: pixel counts that are no multiple of 4 (element-wise stores), feature
+    widths that are multiples of 32 but not of 64 (the small tile with the large volume), single rows and columns,
+    different widths of the two stereo maps -- every one against float64 and, where rows can be cut beforehand, bit for
+    bit against that path."""
+    import random
+    from visual_odometry_amd import ops
+    rnd = random.Random(7)
+    for case in range(10):
+        B, H, W, D = rnd.randint(1, 3), rnd.randint(1, 23), rnd.randint(1, 41), 32 * rnd.randint(1, 8)
+        f1 = (_rand(B, H, W, D, seed=50 + case) * 10.0 ** rnd.uniform(-3, 3)).to(DEV)
+        f2 = (_rand(B, H, W, D, seed=70 + case) * 10.0 ** rnd.uniform(-3, 3)).to(DEV)
+        got = ops.corr_volume_2d(f1, f2, split="f16")
+        want = torch.einsum("bid,bjd->bij", f1.view(B, H * W, D).double(), f2.view(B, H * W, D).double()) / D ** 0.5
+        assert _err(got.view(B, H * W, H * W), want) < F32_GRADE_TOL, (B, H, W, D)
+        if D % 64 == 0:
+            a1, a2 = ops.feature_rows_amax(f1), ops.feature_rows_amax(f2)
+            pre = ops.corr_volume_2d_presplit(ops.split_feature_rows(f1, 32, "f16", a1), ops.split_feature_rows(f2, 32, "f16", a2), "f16", a1, a2)
+            assert torch.equal(pre, got), (B, H, W, D)
+        W2 = rnd.randint(1, 41)
+        g2 = (_rand(B, H, W2, D, seed=90 + case) * 10.0 ** rnd.uniform(-2, 2)).to(DEV)
+        got1 = ops.corr_volume_1d(f1, g2, split="f16")
+        want1 = torch.einsum("bhid,bhjd->bhij", f1.double(), g2.double()) / D ** 0.5
+        assert got1.shape == (B, H, W, W2) and _err(got1, want1) < F32_GRADE_TOL, (B, H, W, W2, D)
