@@ -9,6 +9,8 @@
 // One lane per (pair, level, pixel), lanes along x: the (2r+1)^2 output planes are
 // written fully coalesced (256 B per wave store); the patch reads are 40-byte
 // row segments of that pixel's own slice of the volume (gather, served by L2).
+// All addressing is 32-bit buffer addressing relative to the workgroup's slices (no
+// 64-bit address arithmetic per element, no branch per lane at the slice's edges).
 // Zero padding outside the slice and pixel-centre coordinates, i.e.
 // grid_sample(align_corners=True, padding_mode="zeros") without the normalise /
 // un-normalise round trip.
@@ -22,8 +24,8 @@ struct Levels {
     int w[VO_MAX_LEVELS];
 };
 
-// Level selection by compare/select: indexing the kernel-argument arrays with a
-// per-lane level would spill the struct to scratch memory.
+// Level selection by compare/select on constant indices: indexing the kernel-argument arrays with a variable would
+// copy the struct to scratch memory.  `l` is uniform, so these are scalar selects.
 __device__ __forceinline__ void pick_level(const Levels& lv, int l, const float*& p, int& h, int& w) {
     p = lv.p[0]; h = lv.h[0]; w = lv.w[0];
     if (l == 1) { p = lv.p[1]; h = lv.h[1]; w = lv.w[1]; }
@@ -31,8 +33,11 @@ __device__ __forceinline__ void pick_level(const Levels& lv, int l, const float*
     if (l == 3) { p = lv.p[3]; h = lv.h[3]; w = lv.w[3]; }
 }
 
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PB = 256;                                   // pixels (lanes) per workgroup
+constexpr int OUTSIDE = (int)0x80000000;                  // a buffer offset past every extent: loads give 0, stores are dropped
 
 // floor() of a coordinate as an int that is safe for any input (NaN, inf, huge)
 __device__ __forceinline__ int safe_floor(float v, float& frac) {
@@ -42,105 +47,124 @@ __device__ __forceinline__ int safe_floor(float v, float& frac) {
     return (int)f;
 }
 
-// one patch row of 2R+2 floats starting at column xs (zero outside [0, w))
+// One patch row of 2R+2 floats starting at column xs of the row at byte offset `row_off` (relative to the lane's slice
+// at `pix_off`) of the buffer `rs`; zero outside [0, w) and for rows outside the slice.  No branch per lane: a segment
+// that lies inside its row is three vector loads (row_fast), everything else gets an offset outside the buffer; only when
+// some lane of the wave has a segment that crosses a row end does the wave add ten single loads for those lanes
+// (row_edges; the two results are OR-ed: one of them is all zero bits).  Two steps, so that a caller can request the
+// next row's vector loads before it finishes the current row.
 template <int R>
-__device__ __forceinline__ void load_row(const float* __restrict__ row, int xs, int w, bool row_ok, float (&v)[2 * R + 2]) {
+__device__ __forceinline__ void row_fast(const __amdgpu_buffer_rsrc_t& rs, int seg, bool whole, unsigned (&u)[2 * R + 2]) {
     constexpr int T = 2 * R + 2;
-    if (!row_ok) {
-#pragma unroll
-        for (int i = 0; i < T; ++i) v[i] = 0.0f;
-        return;
-    }
-    if (xs >= 0 && xs + T <= w) {                        // common case: whole segment inside
-        if constexpr (T == 10) {
-            const float4u a = *reinterpret_cast<const float4u*>(row + xs);
-            const float4u b = *reinterpret_cast<const float4u*>(row + xs + 4);
-            const float2u c = *reinterpret_cast<const float2u*>(row + xs + 8);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            v[8] = c.x; v[9] = c.y;
-        } else {
-#pragma unroll
-            for (int i = 0; i < T; ++i) v[i] = row[xs + i];
-        }
+    if constexpr (T == 10) {
+        const int off = whole ? seg : OUTSIDE;
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+        const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs, off + 32, 0, 0);
+        u[0] = a[0]; u[1] = a[1]; u[2] = a[2]; u[3] = a[3]; u[4] = b[0]; u[5] = b[1]; u[6] = b[2]; u[7] = b[3]; u[8] = c[0]; u[9] = c[1];
     } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) u[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, whole ? seg + 4 * i : OUTSIDE, 0, 0);
+    }
+}
+template <int R>
+__device__ __forceinline__ void row_edges(const __amdgpu_buffer_rsrc_t& rs, int seg, int xs, int w, bool partial, unsigned (&u)[2 * R + 2]) {
+    constexpr int T = 2 * R + 2;
+    if (__builtin_amdgcn_ballot_w64(partial) != 0) {
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             const int x = xs + i;
-            v[i] = (x >= 0 && x < w) ? row[x] : 0.0f;
+            u[i] |= __builtin_amdgcn_raw_buffer_load_b32(rs, (partial && x >= 0 && x < w) ? seg + 4 * i : OUTSIDE, 0, 0);
         }
     }
 }
 
-// RPT = window rows (y offsets) per lane.  RPT = 2r+1 gives one lane per (pair,
-// level, pixel); smaller RPT splits a pixel's window over (2r+1)/RPT lanes, which
-// re-reads the shared patch rows from L1 but multiplies the waves in flight.
-template <int R, int RPT>
-__global__ __launch_bounds__(256) void lookup2d_kernel(Levels lv, const float* __restrict__ coords,
-                                                       float* __restrict__ out, int64_t out_bs, int64_t total, int HW, int levels) {
-    constexpr int WIN = 2 * R + 1, T = 2 * R + 2, PARTS = WIN / RPT;
-    static_assert(WIN % RPT == 0, "rows per lane must divide the window");
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int p = (int)(t % HW);
-    const int part = (int)((t / HW) % PARTS);
-    const int l = (int)((t / ((int64_t)HW * PARTS)) % levels);
-    const int64_t b = t / ((int64_t)HW * PARTS * levels);
-
-    const float inv = 1.0f / (float)(1 << l);                       // exact power of two
-    float fx, fy;
-    const int x0 = safe_floor(coords[(b * 2 + 0) * HW + p] * inv, fx);
-    const int y0 = safe_floor(coords[(b * 2 + 1) * HW + p] * inv, fy);
+// One lane per (pair, level, pixel); a workgroup = PB consecutive pixels of one (pair, level), so the level's size and
+// the base of the workgroup's slices are uniform: reads go through one buffer over those PB slices (32-bit offsets, the
+// range check supplies the zeros), the (2r+1)^2 output planes through one buffer over the pair's output with the plane
+// part of the address in the instruction's scalar offset.
+template <int R>
+__global__ __launch_bounds__(PB) void lookup2d_kernel(Levels lv, const float* __restrict__ coords, float* __restrict__ out,
+                                                      int64_t out_bs, int HW, int levels, int blocks_per_image) {
+    constexpr int WIN = 2 * R + 1, T = 2 * R + 2;
+    const int bl = blockIdx.x / blocks_per_image, l = bl % levels, b = bl / levels;
+    const int p0 = (blockIdx.x - bl * blocks_per_image) * PB, lane_p = threadIdx.x, p = p0 + lane_p;
+    const bool live = p < HW;
     int h, w;
-    const float* base;
-    pick_level(lv, l, base, h, w);
-    const float* img = base + (b * HW + p) * (int64_t)h * w;
-    float* o = out + b * out_bs + l * (int64_t)(WIN * WIN) * HW + p;
+    const float* lbase;
+    pick_level(lv, l, lbase, h, w);
+    const int hw4 = h * w * 4;
+    const float* base = lbase + ((int64_t)b * HW + p0) * (int64_t)h * w;
+    const int npix = min(PB, HW - p0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, npix * hw4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)b * out_bs, 0, levels * WIN * WIN * HW * 4, 0x00020000);
 
+    const float inv = 1.0f / (float)(1 << l);                           // exact power of two
+    const int pc = live ? p : HW - 1;
+    float fx, fy;
+    const int x0 = safe_floor(coords[((int64_t)b * 2 + 0) * HW + pc] * inv, fx);
+    const int y0 = safe_floor(coords[((int64_t)b * 2 + 1) * HW + pc] * inv, fy);
     const float wx1 = fx, wx0 = 1.0f - fx, wy1 = fy, wy0 = 1.0f - fy;
-    const int j0 = part * RPT;
-    float prev[WIN], cur[WIN], v[T];
+    const int pix_off = lane_p * hw4;
+    const int ovo = live ? p * 4 : OUTSIDE;
+    const int plane0 = l * WIN * WIN * HW * 4;                            // this level's first output plane
+
+    const int xs = x0 - R;
+    const bool inside = xs >= 0 && xs + T <= w;
+    const int seg0 = pix_off + ((y0 - R) * w + xs) * 4, row4 = w * 4;
+    auto row_ok = [&](int j) { const int y = y0 - R + j; return live && y >= 0 && y < h; };
+    float prev[WIN], cur[WIN];
+    unsigned u[T], un[T];
+    row_fast<R>(rs, seg0, row_ok(0) && inside, u);
 #pragma unroll
-    for (int jj = 0; jj <= RPT; ++jj) {
-        const int j = j0 + jj;
-        const int y = y0 - R + j;
-        load_row<R>(img + (int64_t)y * w, x0 - R, w, y >= 0 && y < h, v);
+    for (int j = 0; j <= WIN; ++j) {
+        if (j < WIN) row_fast<R>(rs, seg0 + (j + 1) * row4, row_ok(j + 1) && inside, un);     // in flight while row j is finished
+        row_edges<R>(rs, seg0 + j * row4, xs, w, row_ok(j) && !inside, u);
 #pragma unroll
-        for (int a = 0; a < WIN; ++a) cur[a] = wx0 * v[a] + wx1 * v[a + 1];
-        if (jj > 0) {
-            // window row j-1 is the y-offset index; the x-offset index a is the slow
-            // channel index: channel = a*(2r+1) + (j-1)
+        for (int a = 0; a < WIN; ++a) cur[a] = wx0 * __uint_as_float(u[a]) + wx1 * __uint_as_float(u[a + 1]);
+        if (j > 0) {
+            // window row j-1 is the y-offset index; the x-offset index a is the slow channel index: channel = a*(2r+1) + (j-1)
 #pragma unroll
-            for (int a = 0; a < WIN; ++a) o[(int64_t)(a * WIN + (j - 1)) * HW] = wy0 * prev[a] + wy1 * cur[a];
+            for (int a = 0; a < WIN; ++a)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wy0 * prev[a] + wy1 * cur[a]), os, ovo, plane0 + (a * WIN + (j - 1)) * HW * 4, 0);
         }
 #pragma unroll
         for (int a = 0; a < WIN; ++a) prev[a] = cur[a];
+#pragma unroll
+        for (int i = 0; i < T; ++i) u[i] = un[i];
     }
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void lookup1d_kernel(Levels lv, const float* __restrict__ coords,
-                                                       float* __restrict__ out, int64_t out_bs, int64_t total, int HW, int levels) {
+__global__ __launch_bounds__(PB) void lookup1d_kernel(Levels lv, const float* __restrict__ coords, float* __restrict__ out,
+                                                      int64_t out_bs, int HW, int levels, int blocks_per_image) {
     constexpr int WIN = 2 * R + 1, T = 2 * R + 2;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int p = (int)(t % HW);
-    const int l = (int)((t / HW) % levels);
-    const int64_t b = t / ((int64_t)HW * levels);
-
+    const int bl = blockIdx.x / blocks_per_image, l = bl % levels, b = bl / levels;
+    const int p0 = (blockIdx.x - bl * blocks_per_image) * PB, lane_p = threadIdx.x, p = p0 + lane_p;
+    const bool live = p < HW;
+    int h, w;
+    const float* lbase;
+    pick_level(lv, l, lbase, h, w);
+    const float* base = lbase + ((int64_t)b * HW + p0) * (int64_t)w;
+    const int npix = min(PB, HW - p0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, npix * w * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(out + (int64_t)b * out_bs, 0, levels * WIN * HW * 4, 0x00020000);
     const float inv = 1.0f / (float)(1 << l);
     float fx;
-    const int x0 = safe_floor(coords[(b * 2 + 0) * HW + p] * inv, fx);
-    int h, w;
-    const float* base;
-    pick_level(lv, l, base, h, w);
-    const float* row = base + (b * HW + p) * (int64_t)w;
+    const int x0 = safe_floor(coords[((int64_t)b * 2 + 0) * HW + (live ? p : HW - 1)] * inv, fx);
+    const int xs = x0 - R, seg = lane_p * w * 4 + xs * 4;
+    const bool inside = xs >= 0 && xs + T <= w;
+    unsigned u[T];
+    row_fast<R>(rs, seg, live && inside, u);
+    row_edges<R>(rs, seg, xs, w, live && !inside, u);
     float v[T];
-    load_row<R>(row, x0 - R, w, true, v);
-    float* o = out + b * out_bs + l * (int64_t)WIN * HW + p;
-    const float wx1 = fx, wx0 = 1.0f - fx;
 #pragma unroll
-    for (int a = 0; a < WIN; ++a) o[(int64_t)a * HW] = wx0 * v[a] + wx1 * v[a + 1];
+    for (int i = 0; i < T; ++i) v[i] = __uint_as_float(u[i]);
+    const float wx1 = fx, wx0 = 1.0f - fx;
+    const int ovo = live ? p * 4 : OUTSIDE;
+#pragma unroll
+    for (int a = 0; a < WIN; ++a)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wx0 * v[a] + wx1 * v[a + 1]), os, ovo, (l * WIN + a) * HW * 4, 0);
 }
 
 int check_common(const char* fn, const float* const* lp, const float* coords, float* out, int batch, int H, int W,
@@ -177,15 +201,17 @@ extern "C" int vo_corr_lookup_2d(const float* l0, const float* l1, const float* 
     // One lane per (pair, level, pixel).  Splitting a window over 3 or 9 lanes was
     // measured slower (58 / 70 us against 52 us at 8 pairs of 640x480): the kernel is
     // bound by the cache lines it pulls in, and split lanes pull shared rows twice.
-    const int64_t total = (int64_t)batch * levels * HW;
-    const int64_t blocks = vo_ceil_div(total, 256);
+    VO_REQUIRE((int64_t)PB * H2 * W2 * 4 < 0x7fffffffLL && (int64_t)levels * (2 * radius + 1) * (2 * radius + 1) * HW * 4 < 0x7fffffffLL,
+               "vo_corr_lookup_2d: a workgroup's slices or one pair's output exceed 2 GiB");
+    const int per_image = (int)vo_ceil_div(HW, PB);
+    const int64_t blocks = (int64_t)per_image * batch * levels;
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_corr_lookup_2d: grid too large");
-    const dim3 grid((unsigned)blocks), block(256);
+    const dim3 grid((unsigned)blocks), block(PB);
     hipStream_t st = vo_stream(stream);
     if (radius == 4)
-        lookup2d_kernel<4, 9><<<grid, block, 0, st>>>(lv, coords, out, out_bs, total, HW, levels);
+        lookup2d_kernel<4><<<grid, block, 0, st>>>(lv, coords, out, out_bs, HW, levels, per_image);
     else
-        lookup2d_kernel<3, 7><<<grid, block, 0, st>>>(lv, coords, out, out_bs, total, HW, levels);
+        lookup2d_kernel<3><<<grid, block, 0, st>>>(lv, coords, out, out_bs, HW, levels, per_image);
     VO_CHECK_LAUNCH("vo_corr_lookup_2d");
     return VO_OK;
 }
@@ -207,13 +233,16 @@ extern "C" int vo_corr_lookup_1d(const float* l0, const float* l1, const float* 
     const int HW = H * W;
     const int64_t out_bs = out_batch_stride ? out_batch_stride : (int64_t)levels * (2 * radius + 1) * HW;
     VO_REQUIRE(out_bs >= (int64_t)levels * (2 * radius + 1) * HW, "vo_corr_lookup_1d: out_batch_stride smaller than one item");
-    const int64_t total = (int64_t)batch * levels * HW;
-    const int64_t blocks = vo_ceil_div(total, 256);
+    VO_REQUIRE((int64_t)PB * W2 * 4 < 0x7fffffffLL && (int64_t)levels * (2 * radius + 1) * HW * 4 < 0x7fffffffLL,
+               "vo_corr_lookup_1d: a workgroup's rows or one pair's output exceed 2 GiB");
+    const int per_image = (int)vo_ceil_div(HW, PB);
+    const int64_t blocks = (int64_t)per_image * batch * levels;
     if (blocks > 0x7fffffffLL) return vo_fail(VO_ERR_UNSUPPORTED, "vo_corr_lookup_1d: grid too large");
+    const dim3 grid((unsigned)blocks), block(PB);
     if (radius == 4)
-        lookup1d_kernel<4><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, out_bs, total, HW, levels);
+        lookup1d_kernel<4><<<grid, block, 0, vo_stream(stream)>>>(lv, coords, out, out_bs, HW, levels, per_image);
     else
-        lookup1d_kernel<3><<<dim3((unsigned)blocks), dim3(256), 0, vo_stream(stream)>>>(lv, coords, out, out_bs, total, HW, levels);
+        lookup1d_kernel<3><<<grid, block, 0, vo_stream(stream)>>>(lv, coords, out, out_bs, HW, levels, per_image);
     VO_CHECK_LAUNCH("vo_corr_lookup_1d");
     return VO_OK;
 }
