@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void instnorm_kernel(T* __restrict__ x, const 
 // Instance norm with known statistics: grid.y = plane, grid.x strides the plane.  With ``skip_stats`` the
 // residual branch too is a raw convolution output with its plane sums: it is normalised (and, with
 // ``skip_relu``, rectified) on the fly, so the branch never exists in normalised form.
-template <typename T>
+// STREAM: the tensor is far larger than the caches -- the raw values and the skip branch are read once, the result is
+// not read again before it has been evicted -- so loads and stores are marked nontemporal (float32 path).
+template <typename T, bool STREAM = false>
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(T* __restrict__ x, const T* __restrict__ skip,
                                                              const double* __restrict__ stats,
                                                              const double* __restrict__ skip_stats, int64_t hw, float eps,
@@ -101,19 +103,37 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(T* __restrict__ x, 
     const int64_t n4 = aligned4<T>(p, q) ? (hw >> 2) : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
     for (int64_t i = t; i < n4; i += stride) {
-        float4 v = vo_ld4<T>(p, i);
+        float4 v;
+        if constexpr (STREAM) {
+            const f32x4_ t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_*>(p) + i);
+            v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        } else {
+            v = vo_ld4<T>(p, i);
+        }
         v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
         if (relu) v = relu4(v);
         if (q) {
-            float4 s = vo_ld4<T>(q, i);
+            float4 s;
+            if constexpr (STREAM) {
+                const f32x4_ t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_*>(q) + i);
+                s = make_float4(t4[0], t4[1], t4[2], t4[3]);
+            } else {
+                s = vo_ld4<T>(q, i);
+            }
             if (skip_stats) {
                 s.x = fmaxf((s.x - sm) * sr, slo); s.y = fmaxf((s.y - sm) * sr, slo);
                 s.z = fmaxf((s.z - sm) * sr, slo); s.w = fmaxf((s.w - sm) * sr, slo);
             }
             v = relu4(add4(v, s));
         }
-        vo_st4<T>(p, i, v);
+        if constexpr (STREAM) {
+            const f32x4_ o4 = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(o4, reinterpret_cast<f32x4_*>(p) + i);
+        } else {
+            vo_st4<T>(p, i, v);
+        }
     }
     for (int64_t i = (n4 << 2) + t; i < hw; i += stride) {
         float v = (vo_ld1(p, i) - m) * r;
@@ -419,6 +439,9 @@ extern "C" int vo_instance_norm_apply(void* x, const void* skip, const double* s
         if (dtype == VO_F16)
             instnorm_apply_kernel<__half><<<grid, dim3(256), 0, vo_stream(stream)>>>((__half*)x, (const __half*)skip, stats, skip_stats, hw,
                                                                                   eps, skip_eps, relu, skip_relu, p0);
+        else if (planes * hw * 4 >= (512LL << 20))
+            instnorm_apply_kernel<float, true><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, stats, skip_stats, hw,
+                                                                                       eps, skip_eps, relu, skip_relu, p0);
         else
             instnorm_apply_kernel<float><<<grid, dim3(256), 0, vo_stream(stream)>>>((float*)x, (const float*)skip, stats, skip_stats, hw,
                                                                                  eps, skip_eps, relu, skip_relu, p0);
