@@ -449,6 +449,8 @@ int vo_corr_pyramid_1d(const float* l0, float* l1, float* l2, float* l3,
  * pyr[l] is level l as produced above; level sizes are floor-halved from (H2,W2).
  * out_batch_stride: elements between the batch items of `out` (0 = dense); larger when `out` is the leading channels of
  * a wider tensor, e.g. the window padded to a multiple of 16 channels for the convolution that consumes it.
+ * Limits (32-bit buffer addressing): 256 * H2 * W2 * 4 bytes (the slices of one workgroup's pixels) and one pair's output
+ * below 2 GiB, i.e. target maps up to about two million pixels; larger sizes are refused with VO_ERR_INVALID_ARG.
  * ------------------------------------------------------------------------- */
 int vo_corr_lookup_2d(const float* l0, const float* l1, const float* l2, const float* l3,
                       const float* coords, float* out, int64_t out_batch_stride, int batch, int H, int W,
