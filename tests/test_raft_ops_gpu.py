@@ -139,6 +139,18 @@ def test_corr_volume_presplit_exact_on_integers_and_1d(vo):
         ops.split_feature_rows(torch.zeros(4, 48, device=DEV), 32)              # D not a multiple of the block
 
 
+def test_lookup_refuses_sizes_beyond_its_32_bit_addressing(vo):
+    """The lookups address a workgroup's 256 slices and one pair's output with 32-bit offsets; a target map whose 256
+    slices exceed 2 GiB is refused before anything is launched (the pointers here are never dereferenced)."""
+    from visual_odometry_amd import _lib
+    t = torch.zeros(64, device=DEV)
+    c = torch.zeros(2 * 4, device=DEV)
+    with pytest.raises(ValueError, match="2 GiB"):
+        _lib.call("vo_corr_lookup_2d", t.data_ptr(), None, None, None, c.data_ptr(), t.data_ptr(), 0, 1, 2, 2, 1500, 1500, 1, 4, None)
+    with pytest.raises(ValueError, match="2 GiB"):
+        _lib.call("vo_corr_lookup_1d", t.data_ptr(), None, None, None, c.data_ptr(), t.data_ptr(), 0, 1, 2, 2, 3000000, 1, 4, None)
+
+
 def test_correlation_chain_properties_at_full_size(vo):
     """The 640x480 geometry (60x80 maps of 256 features, 16 pairs, 1.5 GB of volume), where no CPU restatement
     finishes in seconds: properties that need none.  Scaling a map by a power of two scales the volume exactly
